@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Golden-vector generator -- runs ONLY in the build container (needs /root/reference).
+
+It imports the reference's own Python (with two in-memory stub modules for unrelated imports,
+SURVEY.md section 8c), loads the deterministic weights of
+``universal_speech_enhancement_amd.testing.weights`` into the reference modules, runs them on seeded
+inputs and writes inputs + expected outputs to ``tests/golden/*.npz``.  Nothing of the reference's
+source is copied: the fixtures hold data only.
+
+    python oracle/gen_golden.py [--only NAME]
+
+Fixtures
+  fir.npz           upsample_2d / downsample_2d on [2,5,16,12]                      (G1)
+  resblock_*.npz    ResnetBlockBigGANpp plain / widen / down / up / cat-input        (G1)
+  attn.npz          AttnBlockpp [2,32,8,5]                                          (G1)
+  forward_large.npz NCSNppLarge.forward [2,2,512,64], t in {1.0,0.5} and {0.03,0.2}  (G2)
+  sampler_*.npz     get_pc_sampler with an analytic score_fn, N=7                    (G3)
+  sample_e2e.npz    ScoreModel.sample, 0.4 s utterance, N=3, langevin x1             (G4)
+  sample_cfg1.npz   BASELINE cfg1: 2 s utterance, N=5, reverse_diffusion+langevin    (G5, ~70 s)
+"""
+import argparse
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+for _m in ("torchaudio", "pydub"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+sys.modules["pydub"].AudioSegment = object
+
+import torch  # noqa: E402
+
+from universal_speech_enhancement_amd.testing import noise as tnoise  # noqa: E402
+from universal_speech_enhancement_amd.testing import weights as tw  # noqa: E402
+
+from src.models.components.sgmse import sampling as ref_sampling  # noqa: E402
+from src.models.components.sgmse.backbones.ncsnpp_utils import layerspp, up_or_down_sampling  # noqa: E402
+from src.models.components.sgmse.model_wrapper import ScoreModel  # noqa: E402
+from src.models.components.sgmse.sdes import OUVESDE  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(8)
+
+
+def fill_module(mod: torch.nn.Module, seed: int, tag: str):
+    """Deterministic small-module weights (stored in the fixture as well)."""
+    sd = {}
+    for k, v in mod.state_dict().items():
+        n = v.numel()
+        if v.ndim >= 2:
+            bound = np.sqrt(3.0 / (sum(v.shape[:2]) / 2.0 * max(1, int(np.prod(v.shape[2:])))))
+            a = (tw.uniform01(seed, tag + k, n) * 2 - 1) * bound
+        elif "GroupNorm" in k and k.endswith("weight"):
+            a = 1.0 + 0.2 * (tw.uniform01(seed, tag + k, n) - 0.5)
+        else:
+            a = 0.2 * (tw.uniform01(seed, tag + k, n) - 0.5)
+        sd[k] = torch.from_numpy(a.astype(np.float32).reshape(tuple(v.shape)))
+    mod.load_state_dict(sd)
+    return {k: v.numpy() for k, v in sd.items()}
+
+
+def rnd(seed, tag, shape, scale=1.0):
+    return torch.from_numpy((tnoise.normal(seed, tag, int(np.prod(shape))) * scale).reshape(shape))
+
+
+def gen_fir():
+    x = rnd(1, "fir", (2, 5, 16, 12))
+    up = up_or_down_sampling.upsample_2d(x, [1, 3, 3, 1], factor=2)
+    dn = up_or_down_sampling.downsample_2d(x, [1, 3, 3, 1], factor=2)
+    np.savez(os.path.join(OUT, "fir.npz"), x=x.numpy(), up=up.numpy(), down=dn.numpy())
+
+
+def gen_resblocks():
+    act = torch.nn.SiLU()
+    cases = {"plain": dict(in_ch=16, out_ch=16), "widen": dict(in_ch=16, out_ch=32),
+             "down": dict(in_ch=16, out_ch=16, down=True), "up": dict(in_ch=16, out_ch=16, up=True),
+             "cat": dict(in_ch=48, out_ch=32)}
+    for name, kw in cases.items():
+        blk = layerspp.ResnetBlockBigGANpp(act=act, temb_dim=24, dropout=0.0, fir=True, fir_kernel=[1, 3, 3, 1],
+                                          init_scale=0.0, skip_rescale=True, **kw).eval()
+        w = fill_module(blk, 7, name)
+        x = rnd(2, name + "x", (2, kw["in_ch"], 12, 10))
+        temb = rnd(2, name + "t", (2, 24))
+        with torch.no_grad():
+            y = blk(x, temb)
+        np.savez(os.path.join(OUT, f"resblock_{name}.npz"), x=x.numpy(), temb=temb.numpy(), y=y.numpy(),
+                 **{"w." + k: v for k, v in w.items()})
+
+
+def gen_attn():
+    blk = layerspp.AttnBlockpp(channels=32, skip_rescale=True, init_scale=0.0).eval()
+    w = fill_module(blk, 9, "attn")
+    x = rnd(3, "attnx", (2, 32, 8, 5))
+    with torch.no_grad():
+        y = blk(x)
+    np.savez(os.path.join(OUT, "attn.npz"), x=x.numpy(), y=y.numpy(), **{"w." + k: v for k, v in w.items()})
+
+
+def build_reference_large(seed=1234):
+    m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition="noisy", n_fft=1022, hop_length=160,
+                   num_frames=512, window="hann", sde_input="noisy", predictor="reverse_diffusion",
+                   corrector="langevin").eval()
+    sd = tw.make_state_dict(seed, **tw.LARGE)
+    m.score_net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m, tw.weights_checksum(sd)
+
+
+def gen_forward_large(model=None):
+    m, crc = model or build_reference_large()
+    B, Fq, T = 2, 512, 64
+    x = torch.from_numpy(tnoise.complex_normal(11, "fwd_x", (B, 2, Fq, T))) * 0.5
+    outs = {}
+    with torch.no_grad():
+        for tag, tv in (("a", [1.0, 0.5]), ("b", [0.03, 0.2])):
+            t = torch.tensor(tv, dtype=torch.float32)
+            outs["t_" + tag] = t.numpy()
+            outs["out_" + tag] = m.score_net(x, t).numpy()
+    np.savez(os.path.join(OUT, "forward_large.npz"), x=x.numpy(), weights_seed=1234, weights_crc=crc, **outs)
+
+
+class _Replay:
+    """torch.randn_like replacement that replays a prepared list (and checks shapes)."""
+
+    def __init__(self, draws):
+        self.draws, self.i = draws, 0
+
+    def __call__(self, like, **kw):
+        z = torch.from_numpy(self.draws[self.i]); self.i += 1
+        assert z.shape == like.shape and z.dtype == like.dtype
+        return z
+
+
+def gen_samplers():
+    Y = torch.from_numpy(tnoise.complex_normal(21, "samp_y", (3, 1, 16, 8)))
+    A = torch.from_numpy(tnoise.complex_normal(21, "samp_a", (1, 1, 16, 8)))
+
+    def score_fn(x, t, score_conditioning=None, sde_input=None):  # cheap analytic stand-in
+        return -(x - 0.8 * sde_input) / (0.1 + t[:, None, None, None] ** 2) + 0.05 * A * torch.tanh(x.abs())
+
+    for corr in ("none", "langevin", "ald"):
+        sde = OUVESDE(); sde.N = 7
+        ndraw = 1 + 7 * (1 + (0 if corr == "none" else 2))
+        draws = tnoise.sampler_noise(33, ndraw, tuple(Y.shape))
+        orig = torch.randn_like
+        torch.randn_like = _Replay(list(draws))
+        try:
+            x, nfe = ref_sampling.get_pc_sampler("reverse_diffusion", corr, sde=sde, score_fn=score_fn, y=Y, eps=0.03,
+                                                 snr=0.5, corrector_steps=2, conditioning=[Y])()
+        finally:
+            torch.randn_like = orig
+        np.savez(os.path.join(OUT, f"sampler_rd_{corr}.npz"), Y=Y.numpy(), A=A.numpy(), x=x.numpy(), nfe=nfe,
+                 noise_seed=33, n_draws=ndraw, N=7, corrector_steps=2, snr=0.5, eps=0.03)
+
+
+def _sample_case(m, crc, fname, n_utts, length, N, corrector_steps, seed):
+    wav = torch.from_numpy(tnoise.synth_noisy_speech(n_utts, length, seed=seed))
+    T = 1 + length // 160
+    Tp = (T + 63) // 64 * 64
+    ndraw = 1 + N * (1 + corrector_steps)
+    draws = tnoise.sampler_noise(4321, ndraw, (n_utts, 1, 512, Tp))
+    orig = torch.randn_like
+    torch.randn_like = _Replay(list(draws))
+    try:
+        with torch.no_grad():
+            out = m.sample({"perturbed": wav.clone()}, N=N, corrector_steps=corrector_steps, snr=0.5)["enhanced"]
+    finally:
+        torch.randn_like = orig
+    noise_crc = f"{zlib.crc32(draws.tobytes()) & 0xFFFFFFFF:08x}"
+    np.savez(os.path.join(OUT, fname), wav=wav.numpy(), enhanced=out.numpy(), N=N, corrector_steps=corrector_steps,
+             snr=0.5, noise_seed=4321, n_draws=ndraw, noise_crc=noise_crc, weights_seed=1234, weights_crc=crc,
+             predictor="reverse_diffusion", corrector="langevin")
+
+
+def gen_sample_e2e(model=None):
+    m, crc = model or build_reference_large()
+    _sample_case(m, crc, "sample_e2e.npz", 1, 9600, 3, 1, seed=77)
+
+
+def gen_sample_cfg1(model=None):
+    m, crc = model or build_reference_large()
+    _sample_case(m, crc, "sample_cfg1.npz", 1, 48000, 5, 1, seed=1234)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    small = {"fir": gen_fir, "resblocks": gen_resblocks, "attn": gen_attn, "samplers": gen_samplers}
+    big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1}
+    todo = [a.only] if a.only else list(small) + list(big)
+    model = build_reference_large() if any(n in big for n in todo) else None
+    for n in todo:
+        print("generating", n, flush=True)
+        (small[n]() if n in small else big[n](model))
+    print("done")

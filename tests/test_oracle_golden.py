@@ -1,0 +1,97 @@
+"""Pins the CPU oracle (oracle/*.py) to the reference: every fixture in tests/golden was produced by
+running the reference's own modules (oracle/gen_golden.py, build container only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ncsnpp_oracle as no
+from oracle import sde_oracle as so
+from universal_speech_enhancement_amd.testing import noise as tnoise
+from universal_speech_enhancement_amd.testing import weights as tw
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def test_fir_matches_reference(golden_dir):
+    g = _load(golden_dir, "fir.npz")
+    x = torch.from_numpy(g["x"])
+    np.testing.assert_allclose(no.fir_upsample2(x).numpy(), g["up"], **TOL)
+    np.testing.assert_allclose(no.fir_downsample2(x).numpy(), g["down"], **TOL)
+
+
+@pytest.mark.parametrize("case", ["plain", "widen", "down", "up", "cat"])
+def test_resblock_matches_reference(golden_dir, case):
+    g = _load(golden_dir, f"resblock_{case}.npz")
+    sd = {"blk." + k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w.")}
+    y = no.resblock_biggan(torch.from_numpy(g["x"]), torch.from_numpy(g["temb"]), sd, "blk",
+                           up=(case == "up"), down=(case == "down"))
+    np.testing.assert_allclose(y.numpy(), g["y"], **TOL)
+
+
+def test_attn_matches_reference(golden_dir):
+    g = _load(golden_dir, "attn.npz")
+    sd = {"a." + k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w.")}
+    y = no.attn_block(torch.from_numpy(g["x"]), sd, "a")
+    np.testing.assert_allclose(y.numpy(), g["y"], **TOL)
+
+
+@pytest.mark.parametrize("corr", ["none", "langevin", "ald"])
+def test_sampler_matches_reference(golden_dir, corr):
+    g = _load(golden_dir, f"sampler_rd_{corr}.npz")
+    Y, A = torch.from_numpy(g["Y"]), torch.from_numpy(g["A"])
+    draws = tnoise.sampler_noise(int(g["noise_seed"]), int(g["n_draws"]), tuple(Y.shape))
+
+    def score(x, t):
+        return -(x - 0.8 * Y) / (0.1 + t[:, None, None, None] ** 2) + 0.05 * A * torch.tanh(x.abs())
+
+    x, nfe = so.pc_sampler(score, Y, int(g["N"]), "reverse_diffusion", corr, int(g["corrector_steps"]),
+                           float(g["snr"]), float(g["eps"]), so.NoiseSource(replay=[torch.from_numpy(d) for d in draws]))
+    assert nfe == int(g["nfe"])
+    np.testing.assert_allclose(x.numpy(), g["x"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def large_sd():
+    sd = tw.make_state_dict(1234, **tw.LARGE)
+    return no.to_torch(sd), tw.weights_checksum(sd)
+
+
+def test_weight_recipe_is_stable(golden_dir, large_sd):
+    g = _load(golden_dir, "forward_large.npz")
+    assert str(g["weights_crc"]) == large_sd[1]
+
+
+def test_forward_large_matches_reference(golden_dir, large_sd):
+    g = _load(golden_dir, "forward_large.npz")
+    sd = large_sd[0]
+    x = torch.from_numpy(g["x"])
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    with torch.no_grad():
+        for tag in ("a", "b"):
+            out = no.ncsnpp_forward(sd, x, torch.from_numpy(g["t_" + tag]))
+            ref = g["out_" + tag]
+            err = np.abs(out.numpy() - ref).max() / np.abs(ref).max()
+            assert err < 2e-5, (tag, err)
+
+
+@pytest.mark.slow
+def test_sample_e2e_matches_reference(golden_dir, large_sd):
+    g = _load(golden_dir, "sample_e2e.npz")
+    sd = large_sd[0]
+    wav = torch.from_numpy(g["wav"])
+    Tp = (1 + wav.shape[1] // 160 + 63) // 64 * 64
+    draws = tnoise.sampler_noise(int(g["noise_seed"]), int(g["n_draws"]), (wav.shape[0], 1, 512, Tp))
+    with torch.no_grad():
+        enh, _, _, nfe = so.score_model_sample(lambda x, t: no.ncsnpp_forward(sd, x, t), wav, N=int(g["N"]),
+                                               corrector="langevin", corrector_steps=int(g["corrector_steps"]),
+                                               snr=float(g["snr"]),
+                                               noise=so.NoiseSource(replay=[torch.from_numpy(d) for d in draws]))
+    ref = g["enhanced"]
+    err = np.abs(enh.numpy() - ref).max() / np.abs(ref).max()
+    assert err < 1e-4, err
