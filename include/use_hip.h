@@ -1,0 +1,108 @@
+/* use_hip.h -- C ABI of libuse_hip.so: the MI355X (gfx950) implementation of the SGMSE reverse-SDE
+ * sampling path of nanless/universal-speech-enhancement.
+ *
+ * Boundary (reference file:line, all Python -- the reference has no FFI for this path; the entry points below
+ * are what a ctypes binding of the path binds):
+ *   use_score        <- ScoreModel.forward / forward_score      src/models/components/sgmse/model_wrapper.py:135-145
+ *                       (= -NCSNpp.forward(cat[x, Y], t)         .../backbones/ncsnpp.py:324-501)
+ *   use_sample       <- sampling.get_pc_sampler()->pc_sampler()  .../sampling/__init__.py:23-73
+ *   use_set_weight   <- LightningModule checkpoint load: state_dict keys "all_modules.<i>....", "output_layer.*"
+ *                       (.../backbones/ncsnpp.py:116-316)
+ *   use_sde_*        <- OUVESDE.prior_sampling (sdes.py:248-254), ReverseDiffusionPredictor / EulerMaruyamaPredictor
+ *                       update_fn (sampling/predictors.py:40-68), LangevinCorrector / AnnealedLangevinDynamics
+ *                       update_fn (sampling/correctors.py:37-98)
+ *
+ * Conventions: every function returns 0 on success or a negative USE_E_* code and never throws; the failing
+ * call's message is available from use_last_error() (thread-local).  The caller owns every input / output
+ * buffer and passes raw DEVICE pointers (complex64 spectrograms are [B][1][F][T'] == interleaved (re, im)
+ * floats, T' a multiple of 64) plus the HIP stream to run on; the library owns weights-on-device, workspace and
+ * captured graphs inside the handle.  One handle per (process, device); a handle is not re-entrant.  No call
+ * synchronises the device except use_commit_weights / use_plan / use_destroy.
+ */
+#ifndef USE_HIP_H
+#define USE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct use_handle use_handle;
+typedef void* use_stream_t; /* hipStream_t */
+
+enum { USE_OK = 0, USE_E_INVALID = -1, USE_E_HIP = -2, USE_E_STATE = -3, USE_E_NOMEM = -4 };
+enum { USE_PREC_FP32 = 0, USE_PREC_BF16 = 1 };
+enum { USE_PRED_REVERSE_DIFFUSION = 0, USE_PRED_EULER_MARUYAMA = 1, USE_PRED_NONE = 2 };
+enum { USE_CORR_NONE = 0, USE_CORR_LANGEVIN = 1, USE_CORR_ALD = 2 };
+
+typedef struct use_config {
+    int nf;                /* base width (128)                                   ncsnpp.py:46            */
+    int n_levels;          /* len(ch_mult)                                                             */
+    int ch_mult[8];        /* (1,1,2,2,2,2,2) for NCSNppLarge                    ncsnpp.py:512-517       */
+    int num_res_blocks;    /* 2                                                                        */
+    int n_freq;            /* F = n_fft/2+1 = 512                                SGMSE_Large.yaml:11     */
+    int precision;         /* USE_PREC_*: activation/weight storage; accumulation is always fp32        */
+    float theta, sigma_min, sigma_max; /* OUVE SDE (1.5, 0.05, 0.5)              sdes.py:184             */
+} use_config;
+
+typedef struct use_sampler_config {
+    int N;                 /* reverse steps                                     model_wrapper.py:266    */
+    int predictor;         /* USE_PRED_*                                                               */
+    int corrector;         /* USE_CORR_*                                                               */
+    int corrector_steps;   /* ignored for USE_CORR_NONE                                                */
+    float snr;             /* corrector snr                                                            */
+    float t_eps;           /* smallest time (3e-2)                               model_wrapper.py:27     */
+    int use_graph;         /* 1: capture the whole loop in a hipGraph and replay it                    */
+} use_sampler_config;
+
+const char* use_last_error(void);
+const char* use_version(void);
+
+int use_create(const use_config* cfg, int device, use_handle** out);
+int use_destroy(use_handle* h);
+
+/* Weights.  name = reference state-dict key relative to the score net ("all_modules.4.Conv_0.weight", ...);
+ * data = HOST float32, C-contiguous, shape as in the reference.  use_commit_weights packs (transposes to
+ * [tap][cout][cin], converts to the compute dtype) and uploads one blob. */
+int use_set_weight(use_handle* h, const char* name, const float* data, const int64_t* shape, int ndim);
+int use_commit_weights(use_handle* h);
+/* Multi-GPU: the packed device blob can be broadcast (RCCL) instead of re-packing on every rank:
+ * rank 0 commits, the others call use_alloc_weight_blob, all ranks broadcast [ptr, ptr+bytes). */
+int use_alloc_weight_blob(use_handle* h);
+int use_weight_blob(use_handle* h, void** dev_ptr, size_t* bytes);
+int use_num_expected_weights(use_handle* h);
+int use_expected_weight(use_handle* h, int index, const char** name, int64_t* shape4, int* ndim);
+
+/* Workspace for batch B and T' padded frames (multiple of 64).  Re-planning is allowed. */
+int use_plan(use_handle* h, int B, int Tpad);
+int use_workspace_bytes(use_handle* h, size_t* bytes);
+
+/* One score evaluation: out = -score_net(cat[x, y], t).  x, y, out: complex64 [B,1,F,T']; t: float32 [B] (device). */
+int use_score(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream);
+
+/* Whole PC sampler: prior sampling -> N x (corrector, predictor) -> x_mean of the last predictor step.
+ * noise: complex64 [n_draws][B,1,F,T'] consumed in the reference's order (prior, then per step the corrector
+ * draws followed by the predictor draw), or NULL to draw on-device (Philox4x32-10, `seed`). */
+int use_set_sampler(use_handle* h, const use_sampler_config* sc);
+int use_num_noise_draws(use_handle* h);
+int use_get_timesteps(use_handle* h, float* out, int n);
+int use_sample(use_handle* h, const void* y, const void* noise, uint64_t seed, void* out, use_stream_t stream);
+
+/* Element-wise SDE pieces for callers that drive the loop themselves through the reference's
+ * Predictor / Corrector registries (uniform t over the batch). n = number of complex elements. */
+int use_sde_prior(use_handle* h, const void* y, const void* noise, uint64_t seed, void* x, int64_t n, use_stream_t s);
+int use_sde_predictor(use_handle* h, int predictor, float t, int N, const void* x, const void* y, const void* score,
+                      const void* noise, uint64_t seed, void* x_out, void* x_mean, int64_t n, use_stream_t s);
+int use_sde_corrector(use_handle* h, int corrector, float t, float snr, int B, const void* x, const void* score,
+                      const void* noise, uint64_t seed, void* x_out, void* x_mean, int64_t n, use_stream_t s);
+
+/* Introspection for tests / profiling */
+int use_debug_tensor(use_handle* h, const char* name, void** dev_ptr, int* dims4, int* dtype);
+double use_flops_per_score(use_handle* h);   /* 2*MAC of the conv/linear layers for the current plan */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,85 @@
+"""ctypes binding of libuse_hip.so (C ABI: include/use_hip.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load, importing the product path
+raises -- build it with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C
+universal_speech_enhancement_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuse_hip.so")
+
+PREC = {"fp32": 0, "bf16": 1}
+PREDICTORS = {"reverse_diffusion": 0, "euler_maruyama": 1, "none": 2}
+CORRECTORS = {"none": 0, "langevin": 1, "ald": 2}
+
+
+class UseConfig(C.Structure):
+    _fields_ = [("nf", C.c_int), ("n_levels", C.c_int), ("ch_mult", C.c_int * 8), ("num_res_blocks", C.c_int),
+                ("n_freq", C.c_int), ("precision", C.c_int), ("theta", C.c_float), ("sigma_min", C.c_float),
+                ("sigma_max", C.c_float)]
+
+
+class UseSamplerConfig(C.Structure):
+    _fields_ = [("N", C.c_int), ("predictor", C.c_int), ("corrector", C.c_int), ("corrector_steps", C.c_int),
+                ("snr", C.c_float), ("t_eps", C.c_float), ("use_graph", C.c_int)]
+
+
+class UseHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol declared in include/use_hip.h: (restype, argtypes)
+_vp, _i, _i64, _u64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+SYMBOLS = {
+    "use_last_error": (C.c_char_p, []),
+    "use_version": (C.c_char_p, []),
+    "use_create": (_i, [C.POINTER(UseConfig), _i, C.POINTER(_vp)]),
+    "use_destroy": (_i, [_vp]),
+    "use_set_weight": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
+    "use_commit_weights": (_i, [_vp]),
+    "use_alloc_weight_blob": (_i, [_vp]),
+    "use_weight_blob": (_i, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "use_num_expected_weights": (_i, [_vp]),
+    "use_expected_weight": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i)]),
+    "use_plan": (_i, [_vp, _i, _i]),
+    "use_workspace_bytes": (_i, [_vp, C.POINTER(C.c_size_t)]),
+    "use_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "use_set_sampler": (_i, [_vp, C.POINTER(UseSamplerConfig)]),
+    "use_num_noise_draws": (_i, [_vp]),
+    "use_get_timesteps": (_i, [_vp, C.POINTER(_f), _i]),
+    "use_sample": (_i, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    "use_sde_prior": (_i, [_vp, _vp, _vp, _u64, _vp, _i64, _vp]),
+    "use_sde_predictor": (_i, [_vp, _i, _f, _i, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _i64, _vp]),
+    "use_sde_corrector": (_i, [_vp, _i, _f, _f, _i, _vp, _vp, _vp, _u64, _vp, _vp, _i64, _vp]),
+    "use_debug_tensor": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)]),
+    "use_flops_per_score": (C.c_double, [_vp]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library with typed prototypes; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UseHipError(
+                f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()). "
+                "There is no CPU fallback for the sampling path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> int:
+    if rc < 0:
+        msg = lib().use_last_error().decode(errors="replace")
+        raise UseHipError(f"{what or 'libuse_hip'} failed ({rc}): {msg}")
+    return rc

@@ -1,0 +1,829 @@
+// Host side of libuse_hip.so: NCSN++ architecture walk (reference backbones/ncsnpp.py:116-316, 324-501),
+// weight packing, workspace planning, the score evaluation, the predictor-corrector loop
+// (reference sampling/__init__.py:59-71) with hipGraph capture, and the C ABI of include/use_hip.h.
+#include "../../include/use_hip.h"
+#include "use_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace use;
+
+// ---------------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail(USE_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static inline uint16_t f32_to_bf16(float f) {   // round to nearest even
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// architecture description
+// ---------------------------------------------------------------------------------------------------------
+struct ConvW { std::string wname, bname; int cin = 0, cout = 0, cout_pad = 0, ntaps = 1, w_dtype = DT_F32;
+               bool nin = false; size_t w_off = 0, b_off = 0; };
+struct GNW { std::string prefix; int C = 0; size_t g_off = 0, b_off = 0; };
+struct ResW { int idx = 0, in_ch = 0, out_ch = 0; bool up = false, down = false, has_c2 = false;
+              GNW gn0, gn1; ConvW c0, c1, c2; int dense_row0 = 0; };
+struct CombineW { int idx = 0, C = 0; size_t w_off = 0, b_off = 0; };      // conv1x1 4->C, fp32 [C][4]
+struct AttnW { int idx = 0, C = 0; GNW gn; ConvW q, k, v, o; };
+struct PyrW { GNW gn; ConvW conv; };
+
+struct Expected { std::string name; std::vector<int64_t> shape; };
+
+struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, dtype = DT_F32; float* stats = nullptr; };
+
+struct Arena {
+    char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
+    void reset() { off = 0; }
+    void* alloc(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? (void*)(base + off) : nullptr;
+        off += bytes;
+        if (off > peak) peak = off;
+        return p;
+    }
+};
+
+struct use_handle {
+    use_config cfg{};
+    int device = 0;
+    int act_dtype = DT_F32;
+    // architecture
+    std::vector<Expected> expected;
+    std::unordered_map<std::string, size_t> expected_index;
+    ConvW conv_in;
+    std::vector<ResW> res;            // in forward order
+    std::vector<CombineW> combines;   // one per down level
+    AttnW attn;
+    std::vector<PyrW> pyrs;           // in forward order (coarsest level first)
+    int dense_rows = 0;
+    size_t gfp_off = 0, l1w_off = 0, l1b_off = 0, l2w_off = 0, l2b_off = 0, dense_w_off = 0, dense_b_off = 0,
+           outw_off = 0, outb_off = 0;
+    size_t blob_bytes = 0;
+    // weights
+    std::unordered_map<std::string, std::vector<float>> host_w;
+    char* blob = nullptr; bool weights_ready = false;
+    // plan
+    int B = 0, T = 0;
+    Arena arena;
+    char* persist = nullptr; size_t persist_bytes = 0;
+    float *x4 = nullptr, *silu_temb = nullptr, *tembias = nullptr, *t_dev = nullptr;
+    float2 *Y = nullptr, *X = nullptr, *Xmean = nullptr, *score = nullptr, *xin = nullptr;
+    float *lang_partial = nullptr, *lang_step = nullptr;
+    unsigned long long* rng_state = nullptr;
+    int lang_blocks = 0;
+    // sampler
+    use_sampler_config sc{};
+    bool sampler_set = false;
+    std::vector<float> timesteps;
+    float* ts_dev = nullptr; float* temb_table = nullptr; float* silu_table = nullptr;
+    float2* noise_copy = nullptr; size_t noise_copy_bytes = 0;
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // [0]: device RNG, [1]: injected noise
+    hipGraphExec_t score_graph = nullptr;
+    // scratch for the stand-alone use_sde_* entry points (independent of weights / plan)
+    char* sde_buf = nullptr; unsigned long long* sde_rng = nullptr; float* sde_step = nullptr; float* sde_partial = nullptr;
+    static constexpr int SDE_MAX_B = 1024, SDE_BLOCKS = 128;
+    // introspection
+    bool dry = false;
+    std::map<std::string, Act> debug;
+    double flops = 0.0;
+};
+
+static void add_expected(use_handle* h, const std::string& name, std::vector<int64_t> shape) {
+    h->expected_index[name] = h->expected.size();
+    h->expected.push_back({name, std::move(shape)});
+}
+
+static ConvW make_conv(use_handle* h, const std::string& prefix, int cin, int cout, int ntaps, int w_dtype) {
+    ConvW c; c.wname = prefix + ".weight"; c.bname = prefix + ".bias"; c.cin = cin; c.cout = cout; c.ntaps = ntaps;
+    c.w_dtype = w_dtype;
+    c.cout_pad = cout <= 32 ? 32 : (cout + 127) / 128 * 128;
+    const int k = ntaps == 9 ? 3 : 1;
+    add_expected(h, c.wname, {cout, cin, k, k});
+    add_expected(h, c.bname, {cout});
+    return c;
+}
+static ConvW make_nin(use_handle* h, const std::string& prefix, int C, int w_dtype) {
+    ConvW c; c.wname = prefix + ".W"; c.bname = prefix + ".b"; c.cin = C; c.cout = C; c.ntaps = 1; c.w_dtype = w_dtype;
+    c.nin = true; c.cout_pad = (C + 127) / 128 * 128;
+    add_expected(h, c.wname, {C, C});
+    add_expected(h, c.bname, {C});
+    return c;
+}
+static GNW make_gn(use_handle* h, const std::string& prefix, int C) {
+    GNW g; g.prefix = prefix; g.C = C;
+    add_expected(h, prefix + ".weight", {C});
+    add_expected(h, prefix + ".bias", {C});
+    return g;
+}
+
+static ResW make_res(use_handle* h, int idx, int in_ch, int out_ch, bool up, bool down) {
+    const std::string p = "all_modules." + std::to_string(idx);
+    const int dt = h->act_dtype;
+    ResW r; r.idx = idx; r.in_ch = in_ch; r.out_ch = out_ch; r.up = up; r.down = down;
+    r.gn0 = make_gn(h, p + ".GroupNorm_0", in_ch);
+    r.c0 = make_conv(h, p + ".Conv_0", in_ch, out_ch, 9, dt);
+    add_expected(h, p + ".Dense_0.weight", {out_ch, 4 * h->cfg.nf});
+    add_expected(h, p + ".Dense_0.bias", {out_ch});
+    r.dense_row0 = h->dense_rows; h->dense_rows += out_ch;
+    r.gn1 = make_gn(h, p + ".GroupNorm_1", out_ch);
+    r.c1 = make_conv(h, p + ".Conv_1", out_ch, out_ch, 9, dt);
+    r.has_c2 = (in_ch != out_ch) || up || down;
+    if (r.has_c2) r.c2 = make_conv(h, p + ".Conv_2", in_ch, out_ch, 1, dt);
+    return r;
+}
+
+// Mirrors the module construction order of reference ncsnpp.py:181-316.
+static int build_arch(use_handle* h) {
+    const use_config& c = h->cfg;
+    const int nf = c.nf, L = c.n_levels, nrb = c.num_res_blocks, dt = h->act_dtype;
+    add_expected(h, "output_layer.weight", {2, 4, 1, 1});
+    add_expected(h, "output_layer.bias", {2});
+    int m = 0;
+    add_expected(h, "all_modules.0.W", {nf}); m++;
+    add_expected(h, "all_modules.1.weight", {4 * nf, 2 * nf}); add_expected(h, "all_modules.1.bias", {4 * nf}); m++;
+    add_expected(h, "all_modules.2.weight", {4 * nf, 4 * nf}); add_expected(h, "all_modules.2.bias", {4 * nf}); m++;
+    h->conv_in = make_conv(h, "all_modules." + std::to_string(m), 4, nf, 9, DT_F32); m++;   // fp32 input always
+    std::vector<int> hs_c{nf};
+    int in_ch = nf;
+    for (int lvl = 0; lvl < L; ++lvl) {
+        for (int k = 0; k < nrb; ++k) {
+            const int out_ch = nf * c.ch_mult[lvl];
+            h->res.push_back(make_res(h, m++, in_ch, out_ch, false, false));
+            in_ch = out_ch; hs_c.push_back(in_ch);
+        }
+        if (lvl != L - 1) {
+            h->res.push_back(make_res(h, m++, in_ch, in_ch, false, true));
+            CombineW cb; cb.idx = m; cb.C = in_ch;
+            add_expected(h, "all_modules." + std::to_string(m) + ".Conv_0.weight", {in_ch, 4, 1, 1});
+            add_expected(h, "all_modules." + std::to_string(m) + ".Conv_0.bias", {in_ch});
+            h->combines.push_back(cb); m++;
+            hs_c.push_back(in_ch);
+        }
+    }
+    in_ch = hs_c.back();
+    h->res.push_back(make_res(h, m++, in_ch, in_ch, false, false));
+    {
+        const std::string p = "all_modules." + std::to_string(m);
+        h->attn.idx = m; h->attn.C = in_ch;
+        h->attn.gn = make_gn(h, p + ".GroupNorm_0", in_ch);
+        h->attn.q = make_nin(h, p + ".NIN_0", in_ch, dt);
+        h->attn.k = make_nin(h, p + ".NIN_1", in_ch, dt);
+        h->attn.v = make_nin(h, p + ".NIN_2", in_ch, dt);
+        h->attn.o = make_nin(h, p + ".NIN_3", in_ch, dt);
+        m++;
+    }
+    h->res.push_back(make_res(h, m++, in_ch, in_ch, false, false));
+    for (int lvl = L - 1; lvl >= 0; --lvl) {
+        for (int k = 0; k < nrb + 1; ++k) {
+            const int out_ch = nf * c.ch_mult[lvl];
+            const int skip = hs_c.back(); hs_c.pop_back();
+            h->res.push_back(make_res(h, m++, in_ch + skip, out_ch, false, false));
+            in_ch = out_ch;
+        }
+        PyrW pw;
+        pw.gn = make_gn(h, "all_modules." + std::to_string(m), in_ch); m++;
+        pw.conv = make_conv(h, "all_modules." + std::to_string(m), in_ch, 4, 9, dt); m++;
+        h->pyrs.push_back(pw);
+        if (lvl != 0) h->res.push_back(make_res(h, m++, in_ch, in_ch, true, false));
+    }
+    if (!hs_c.empty()) return fail(USE_E_INVALID, "internal: skip stack not empty");
+
+    // ---- device blob layout ----
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; size_t o = off; off += bytes; return o; };
+    auto lay_conv = [&](ConvW& w) {
+        w.w_off = take((size_t)w.ntaps * w.cout_pad * w.cin * dtype_size(w.w_dtype));
+        w.b_off = take((size_t)w.cout * 4);
+    };
+    auto lay_gn = [&](GNW& g) { g.g_off = take((size_t)g.C * 4); g.b_off = take((size_t)g.C * 4); };
+    h->outw_off = take(8 * 4); h->outb_off = take(2 * 4);
+    h->gfp_off = take((size_t)nf * 4);
+    h->l1w_off = take((size_t)4 * nf * 2 * nf * 4); h->l1b_off = take((size_t)4 * nf * 4);
+    h->l2w_off = take((size_t)4 * nf * 4 * nf * 4); h->l2b_off = take((size_t)4 * nf * 4);
+    h->dense_w_off = take((size_t)h->dense_rows * 4 * nf * 4); h->dense_b_off = take((size_t)h->dense_rows * 4);
+    lay_conv(h->conv_in);
+    for (auto& r : h->res) { lay_gn(r.gn0); lay_conv(r.c0); lay_gn(r.gn1); lay_conv(r.c1); if (r.has_c2) lay_conv(r.c2); }
+    for (auto& cb : h->combines) { cb.w_off = take((size_t)cb.C * 4 * 4); cb.b_off = take((size_t)cb.C * 4); }
+    lay_gn(h->attn.gn); lay_conv(h->attn.q); lay_conv(h->attn.k); lay_conv(h->attn.v); lay_conv(h->attn.o);
+    for (auto& p : h->pyrs) { lay_gn(p.gn); lay_conv(p.conv); }
+    h->blob_bytes = (off + 255) & ~(size_t)255;
+    return USE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------------------
+static void pack_conv(const use_handle* h, const ConvW& w, char* blob) {
+    const std::vector<float>& src = h->host_w.at(w.wname);
+    const std::vector<float>& bias = h->host_w.at(w.bname);
+    const size_t es = dtype_size(w.w_dtype);
+    char* dst = blob + w.w_off;
+    memset(dst, 0, (size_t)w.ntaps * w.cout_pad * w.cin * es);
+    for (int tap = 0; tap < w.ntaps; ++tap)
+        for (int co = 0; co < w.cout; ++co)
+            for (int ci = 0; ci < w.cin; ++ci) {
+                // reference conv weight [cout][cin][kh][kw]; NIN W is [cin][cout] (layers.py:639-650)
+                const float v = w.nin ? src[(size_t)ci * w.cout + co] : src[((size_t)co * w.cin + ci) * w.ntaps + tap];
+                const size_t o = ((size_t)tap * w.cout_pad + co) * w.cin + ci;
+                if (w.w_dtype == DT_F32) ((float*)dst)[o] = v; else ((uint16_t*)dst)[o] = f32_to_bf16(v);
+            }
+    memcpy(blob + w.b_off, bias.data(), (size_t)w.cout * 4);
+}
+static void pack_gn(const use_handle* h, const GNW& g, char* blob) {
+    memcpy(blob + g.g_off, h->host_w.at(g.prefix + ".weight").data(), (size_t)g.C * 4);
+    memcpy(blob + g.b_off, h->host_w.at(g.prefix + ".bias").data(), (size_t)g.C * 4);
+}
+
+static int pack_all(use_handle* h, char* blob) {
+    for (const auto& e : h->expected)
+        if (!h->host_w.count(e.name)) return fail(USE_E_STATE, "weight '%s' was never set", e.name.c_str());
+    const int nf = h->cfg.nf;
+    auto cp = [&](size_t off, const char* name) {
+        const auto& v = h->host_w.at(name); memcpy(blob + off, v.data(), v.size() * 4);
+    };
+    cp(h->outw_off, "output_layer.weight"); cp(h->outb_off, "output_layer.bias");
+    cp(h->gfp_off, "all_modules.0.W");
+    cp(h->l1w_off, "all_modules.1.weight"); cp(h->l1b_off, "all_modules.1.bias");
+    cp(h->l2w_off, "all_modules.2.weight"); cp(h->l2b_off, "all_modules.2.bias");
+    pack_conv(h, h->conv_in, blob);
+    for (const auto& r : h->res) {
+        pack_gn(h, r.gn0, blob); pack_conv(h, r.c0, blob); pack_gn(h, r.gn1, blob); pack_conv(h, r.c1, blob);
+        if (r.has_c2) pack_conv(h, r.c2, blob);
+        const std::string p = "all_modules." + std::to_string(r.idx);
+        memcpy(blob + h->dense_w_off + (size_t)r.dense_row0 * 4 * nf * 4, h->host_w.at(p + ".Dense_0.weight").data(),
+               (size_t)r.out_ch * 4 * nf * 4);
+        memcpy(blob + h->dense_b_off + (size_t)r.dense_row0 * 4, h->host_w.at(p + ".Dense_0.bias").data(),
+               (size_t)r.out_ch * 4);
+    }
+    for (const auto& cb : h->combines) {
+        const std::string p = "all_modules." + std::to_string(cb.idx);
+        cp(cb.w_off, (p + ".Conv_0.weight").c_str()); cp(cb.b_off, (p + ".Conv_0.bias").c_str());
+    }
+    pack_gn(h, h->attn.gn, blob);
+    pack_conv(h, h->attn.q, blob); pack_conv(h, h->attn.k, blob); pack_conv(h, h->attn.v, blob); pack_conv(h, h->attn.o, blob);
+    for (const auto& p : h->pyrs) { pack_gn(h, p.gn, blob); pack_conv(h, p.conv, blob); }
+    return USE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward pass (one score-network evaluation)
+// ---------------------------------------------------------------------------------------------------------
+struct Fwd {
+    use_handle* h; hipStream_t s;
+    const float* tembias; int temb_bstride;      // [B or 1][dense_rows]
+    const float* t; int t_stride;                 // per-item time (stride 0: shared)
+    template <typename T> const T* W(size_t off) const { return (const T*)(h->blob + off); }
+
+    Act new_act(int C, int H, int Wd, int dtype, bool stats) {
+        Act a; a.C = C; a.H = H; a.W = Wd; a.dtype = dtype;
+        a.p = h->arena.alloc((size_t)h->B * H * Wd * C * dtype_size(dtype));
+        if (stats) a.stats = (float*)h->arena.alloc((size_t)h->B * tiles_per_image(H, Wd) * C * 2 * 4);
+        return a;
+    }
+
+    float* gn_coef(const Act& a, const Act* a2, const GNW& g) {
+        const int C = a.C + (a2 ? a2->C : 0);
+        float* coef = (float*)h->arena.alloc((size_t)h->B * C * 2 * 4);
+        if (!h->dry)
+            launch_gn_finalize(a.stats, a.C, a2 ? a2->stats : nullptr, a2 ? a2->C : 0, tiles_per_image(a.H, a.W),
+                               W<float>(g.g_off), W<float>(g.b_off), std::min(C / 4, 32), a.H * a.W, 1e-6f, coef,
+                               h->B, s);
+        return coef;
+    }
+
+    Act conv(const Act& a, const Act* a2, const float* coef, int act, const ConvW& w, const float* temb,
+             const Act* res, float scale, const float* pyr, const CombineW* cb, int out_dtype, bool stats) {
+        Act o = new_act(w.cout, a.H, a.W, out_dtype, stats);
+        h->flops += 2.0 * h->B * a.H * a.W * (double)w.cout * w.cin * w.ntaps;
+        if (h->dry) return o;
+        ConvArgs p{};
+        p.src0 = a.p; p.C0 = a.C; p.src1 = a2 ? a2->p : nullptr; p.C1 = a2 ? a2->C : 0; p.in_dtype = a.dtype;
+        p.coef = coef; p.act = act; p.w = h->blob + w.w_off; p.cout_pad = w.cout_pad; p.bias = W<float>(w.b_off);
+        p.temb = temb; p.temb_bstride = temb_bstride;
+        p.res = res ? res->p : nullptr; p.out_scale = scale;
+        p.pyr = pyr; p.w4 = cb ? W<float>(cb->w_off) : nullptr; p.b4 = cb ? W<float>(cb->b_off) : nullptr;
+        p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
+        p.B = h->B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
+        launch_conv(p, s);
+        return o;
+    }
+
+    // ResnetBlockBigGANpp.forward (reference layerspp.py:282-314). `skip` = second half of the channel concat.
+    Act resblock(const Act& x, const Act* skip, const ResW& r, const float* pyr = nullptr, const CombineW* cb = nullptr) {
+        const float rs = 0.70710678118654752440f;   // 1/sqrt(2)
+        const float* temb = tembias + r.dense_row0;
+        float* coef0 = gn_coef(x, skip, r.gn0);
+        const int dt = h->act_dtype;
+        Act hcur, xres;
+        if (r.up || r.down) {
+            const int H2 = r.up ? x.H * 2 : x.H / 2, W2 = r.up ? x.W * 2 : x.W / 2;
+            Act hr = new_act(x.C, H2, W2, dt, false), xr = new_act(x.C, H2, W2, dt, false);
+            if (!h->dry) {
+                if (r.up) launch_fir_up2(x.p, dt, coef0, 1, hr.p, xr.p, h->B, x.H, x.W, x.C, s);
+                else      launch_fir_down2(x.p, dt, coef0, 1, hr.p, xr.p, h->B, x.H, x.W, x.C, s);
+            }
+            hcur = conv(hr, nullptr, nullptr, 0, r.c0, temb, nullptr, 1.f, nullptr, nullptr, dt, true);
+            xres = conv(xr, nullptr, nullptr, 0, r.c2, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
+        } else {
+            hcur = conv(x, skip, coef0, 1, r.c0, temb, nullptr, 1.f, nullptr, nullptr, dt, true);
+            xres = r.has_c2 ? conv(x, skip, nullptr, 0, r.c2, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false) : x;
+        }
+        float* coef1 = gn_coef(hcur, nullptr, r.gn1);
+        return conv(hcur, nullptr, coef1, 1, r.c1, nullptr, &xres, rs, pyr, cb, dt, true);
+    }
+
+    // AttnBlockpp.forward (reference layerspp.py:77-93)
+    Act attention(const Act& x, const AttnW& aw) {
+        const int dt = h->act_dtype;
+        float* coef = gn_coef(x, nullptr, aw.gn);
+        Act q = conv(x, nullptr, coef, 0, aw.q, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
+        Act k = conv(x, nullptr, coef, 0, aw.k, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
+        Act v = conv(x, nullptr, coef, 0, aw.v, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
+        Act a = new_act(x.C, x.H, x.W, dt, false);
+        if (!h->dry) launch_attention(q.p, k.p, v.p, a.p, dt, h->B, x.H * x.W, x.C, s);
+        return conv(a, nullptr, nullptr, 0, aw.o, nullptr, &x, 0.70710678118654752440f, nullptr, nullptr, dt, true);
+    }
+
+    // NCSNpp.forward (reference ncsnpp.py:324-501): x4 = packed network input, returns the fp32 pyramid [B,F,T,4]
+    Act run(const float* x4) {
+        use_handle* H = h;
+        const use_config& c = H->cfg;
+        const int L = c.n_levels, nrb = c.num_res_blocks, dt = H->act_dtype;
+        H->arena.reset(); H->flops = 0.0; H->debug.clear();
+        Act xin; xin.p = (void*)x4; xin.C = 4; xin.H = c.n_freq; xin.W = H->T; xin.dtype = DT_F32;
+        std::vector<Act> hs;
+        hs.push_back(conv(xin, nullptr, nullptr, 0, H->conv_in, nullptr, nullptr, 1.f, nullptr, nullptr, dt, true));
+        H->debug["h_in"] = hs.back();
+        Act ipyr = xin;
+        size_t ri = 0, ci = 0;
+        for (int lvl = 0; lvl < L; ++lvl) {
+            for (int k = 0; k < nrb; ++k) hs.push_back(resblock(hs.back(), nullptr, H->res[ri++]));
+            if (lvl != L - 1) {
+                Act nip = new_act(4, ipyr.H / 2, ipyr.W / 2, DT_F32, false);          // pyramid_downsample
+                if (!H->dry) launch_fir_down2(ipyr.p, DT_F32, nullptr, 0, nullptr, nip.p, H->B, ipyr.H, ipyr.W, 4, s);
+                ipyr = nip;
+                hs.push_back(resblock(hs.back(), nullptr, H->res[ri++], (const float*)ipyr.p, &H->combines[ci++]));
+            }
+        }
+        H->debug["down_out"] = hs.back();
+        Act hc = resblock(hs.back(), nullptr, H->res[ri++]);
+        H->debug["pre_attn"] = hc;
+        hc = attention(hc, H->attn);
+        H->debug["post_attn"] = hc;
+        hc = resblock(hc, nullptr, H->res[ri++]);
+        Act pyr; bool have_pyr = false; size_t pi = 0;
+        for (int lvl = L - 1; lvl >= 0; --lvl) {
+            for (int k = 0; k < nrb + 1; ++k) {
+                Act sk = hs.back(); hs.pop_back();
+                hc = resblock(hc, &sk, H->res[ri++]);
+            }
+            const PyrW& pw = H->pyrs[pi++];
+            float* coef = gn_coef(hc, nullptr, pw.gn);
+            if (!have_pyr) {
+                pyr = conv(hc, nullptr, coef, 1, pw.conv, nullptr, nullptr, 1.f, nullptr, nullptr, DT_F32, false);
+                have_pyr = true;
+            } else {
+                Act up = new_act(4, pyr.H * 2, pyr.W * 2, DT_F32, false);               // pyramid_upsample
+                if (!H->dry) launch_fir_up2(pyr.p, DT_F32, nullptr, 0, nullptr, up.p, H->B, pyr.H, pyr.W, 4, s);
+                pyr = conv(hc, nullptr, coef, 1, pw.conv, nullptr, &up, 1.f, nullptr, nullptr, DT_F32, false);
+            }
+            if (lvl != 0) hc = resblock(hc, nullptr, H->res[ri++]);
+        }
+        H->debug["h_last"] = hc;
+        H->debug["pyramid"] = pyr;
+        return pyr;
+    }
+};
+
+// time embedding for `rows` time values (batch items, or sampler steps) -> tembias[rows][dense_rows]
+static void run_temb(use_handle* h, const float* t, int n, float* silu_buf, float* out, hipStream_t s) {
+    const int nf = h->cfg.nf;
+    launch_temb_mlp(t, 1, (const float*)(h->blob + h->gfp_off), (const float*)(h->blob + h->l1w_off),
+                    (const float*)(h->blob + h->l1b_off), (const float*)(h->blob + h->l2w_off),
+                    (const float*)(h->blob + h->l2b_off), silu_buf, n, nf, s);
+    launch_temb_dense(silu_buf, (const float*)(h->blob + h->dense_w_off), (const float*)(h->blob + h->dense_b_off), out,
+                      n, h->dense_rows, 4 * nf, s);
+}
+
+// score = -net(cat[x, y], t): x, y device complex64
+static void run_score(use_handle* h, const float2* x, const float2* y, const float* tembias, int temb_bstride,
+                      const float* t, int t_stride, float2* out, hipStream_t s) {
+    const long npix = (long)h->B * h->cfg.n_freq * h->T;
+    launch_pack_input(x, y, h->x4, npix, s);
+    Fwd f{h, s, tembias, temb_bstride, t, t_stride};
+    Act pyr = f.run(h->x4);
+    launch_score_out((const float*)pyr.p, t, t_stride, (const float*)(h->blob + h->outw_off),
+                     (const float*)(h->blob + h->outb_off), out, h->B, (long)h->cfg.n_freq * h->T, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SDE scalars (reference sdes.py:205-243, 88-92)
+// ---------------------------------------------------------------------------------------------------------
+static double ouve_logsig(const use_config& c) { return std::log((double)c.sigma_max / (double)c.sigma_min); }
+static float ouve_std(const use_config& c, float t) {
+    const double th = c.theta, ls = ouve_logsig(c), sm = c.sigma_min, tt = t;
+    return (float)std::sqrt(sm * sm * std::exp(-2 * th * tt) * (std::exp(2 * (th + ls) * tt) - 1) * ls / (th + ls));
+}
+static float ouve_diffusion(const use_config& c, float t) {
+    const float sigma = c.sigma_min * std::pow(c.sigma_max / c.sigma_min, t);     // float32 like the reference
+    return (float)((double)sigma * std::sqrt(2 * ouve_logsig(c)));
+}
+// torch.linspace(start, end, steps) float32 CPU semantics (symmetric fill from both ends)
+static void linspace_f32(float start, float end, int steps, std::vector<float>& out) {
+    out.resize(steps);
+    if (steps == 1) { out[0] = start; return; }
+    const float step = (end - start) / (float)(steps - 1);
+    const int half = steps / 2;
+    for (int i = 0; i < steps; ++i) out[i] = i < half ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+}
+
+static void predictor_coeffs(const use_config& c, int predictor, float t, int N, float& cd, float& cs, float& cn) {
+    const float g = ouve_diffusion(c, t);
+    if (predictor == USE_PRED_REVERSE_DIFFUSION) {            // predictors.py:61-68 over sdes.py:88-92,159-173
+        const float dt = (float)(1.0 / N);
+        const float G = g * std::sqrt(dt);
+        cd = c.theta * dt; cs = G * G; cn = G;
+    } else {                                                  // Euler-Maruyama: predictors.py:44-53, sdes.py:125-157
+        const double dt = 1.0 / N;
+        cd = (float)(c.theta * dt); cs = (float)((double)(g * g) * dt); cn = (float)((double)g * std::sqrt(dt));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the PC loop (reference sampling/__init__.py:59-71)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void set_rng_kernel(unsigned long long* st, unsigned long long seed, unsigned long long base) { st[0] = seed; st[1] = base; }
+
+static void run_sampler(use_handle* h, const float2* noise, hipStream_t s) {
+    const use_sampler_config& sc = h->sc;
+    const long n = (long)h->B * h->cfg.n_freq * h->T, n_per_b = (long)h->cfg.n_freq * h->T;
+    const int ncorr = sc.corrector == USE_CORR_NONE ? 0 : sc.corrector_steps;
+    auto nz = [&](unsigned d) { return noise ? noise + (size_t)d * n : nullptr; };
+    unsigned d = 0;
+    launch_prior(h->Y, nz(d), RngRef{h->rng_state, d}, ouve_std(h->cfg, 1.0f), h->X, n, s); d++;
+    for (int i = 0; i < sc.N; ++i) {
+        const float t = h->timesteps[i];
+        const float* temb = h->temb_table + (size_t)i * h->dense_rows;
+        for (int k = 0; k < ncorr; ++k) {
+            run_score(h, h->X, h->Y, temb, 0, h->ts_dev + i, 0, h->score, s);
+            RngRef rr{h->rng_state, d};
+            if (sc.corrector == USE_CORR_LANGEVIN) {
+                launch_langevin_norms(h->score, nz(d), rr, h->lang_partial, h->B, n_per_b, h->lang_blocks, s);
+                launch_langevin_step(h->lang_partial, h->B, h->lang_blocks, sc.snr, h->lang_step, s);
+                launch_corrector(h->X, h->score, nz(d), rr, h->lang_step, 0.f, h->X, nullptr, n, s);
+            } else {                                               // ALD: correctors.py:79-98
+                const float sd = sc.snr * ouve_std(h->cfg, t);
+                launch_corrector(h->X, h->score, nz(d), rr, nullptr, sd * sd * 2.f, h->X, nullptr, n, s);
+            }
+            d++;
+        }
+        if (sc.predictor == USE_PRED_NONE) {
+            if (i == sc.N - 1) (void)hipMemcpyAsync(h->Xmean, h->X, (size_t)n * 8, hipMemcpyDeviceToDevice, s);
+        } else {
+            run_score(h, h->X, h->Y, temb, 0, h->ts_dev + i, 0, h->score, s);
+            float cd, cs, cn; predictor_coeffs(h->cfg, sc.predictor, t, sc.N, cd, cs, cn);
+            launch_predictor(h->X, h->Y, h->score, nz(d), RngRef{h->rng_state, d}, cd, cs, cn, h->X,
+                             i == sc.N - 1 ? h->Xmean : nullptr, n, s);
+            d++;
+        }
+    }
+}
+
+static void drop_graphs(use_handle* h) {
+    for (auto& g : h->graph_exec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    if (h->score_graph) { (void)hipGraphExecDestroy(h->score_graph); h->score_graph = nullptr; }
+}
+
+static int ensure_sde_scratch(use_handle* h) {
+    if (!h) return fail(USE_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->sde_buf) {
+        const size_t bytes = 512 + (size_t)use_handle::SDE_MAX_B * use_handle::SDE_BLOCKS * 2 * 4;
+        HIPCHK(hipMalloc((void**)&h->sde_buf, bytes));
+        HIPCHK(hipMemset(h->sde_buf, 0, bytes));
+        h->sde_rng = (unsigned long long*)h->sde_buf; h->sde_step = (float*)(h->sde_buf + 256);
+        h->sde_partial = (float*)(h->sde_buf + 512);
+    }
+    return USE_OK;
+}
+
+static int ensure_cap_stream(use_handle* h) {
+    if (!h->cap_stream) HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    return USE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* use_last_error(void) { return g_err.c_str(); }
+const char* use_version(void) { return "use_hip 0.1 (gfx950)"; }
+
+int use_create(const use_config* cfg, int device, use_handle** out) {
+    if (!cfg || !out) return fail(USE_E_INVALID, "null argument");
+    if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->nf % 64 != 0 || cfg->num_res_blocks < 1)
+        return fail(USE_E_INVALID, "unsupported architecture (nf must be a multiple of 64, 1..8 levels)");
+    if (cfg->n_freq % (1 << (cfg->n_levels - 1)) != 0)
+        return fail(USE_E_INVALID, "n_freq=%d is not divisible by 2^(levels-1)", cfg->n_freq);
+    if (cfg->precision != USE_PREC_FP32 && cfg->precision != USE_PREC_BF16) return fail(USE_E_INVALID, "bad precision");
+    use_handle* h = new use_handle();
+    h->cfg = *cfg; h->device = device;
+    h->act_dtype = cfg->precision == USE_PREC_BF16 ? DT_BF16 : DT_F32;
+    int rc = build_arch(h);
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return USE_OK;
+}
+
+int use_destroy(use_handle* h) {
+    if (!h) return USE_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    drop_graphs(h);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->blob) (void)hipFree(h->blob);
+    if (h->arena.base) (void)hipFree(h->arena.base);
+    if (h->persist) (void)hipFree(h->persist);
+    if (h->temb_table) (void)hipFree(h->temb_table);
+    if (h->silu_table) (void)hipFree(h->silu_table);
+    if (h->ts_dev) (void)hipFree(h->ts_dev);
+    if (h->noise_copy) (void)hipFree(h->noise_copy);
+    if (h->sde_buf) (void)hipFree(h->sde_buf);
+    delete h;
+    return USE_OK;
+}
+
+int use_num_expected_weights(use_handle* h) { return h ? (int)h->expected.size() : USE_E_INVALID; }
+int use_expected_weight(use_handle* h, int index, const char** name, int64_t* shape4, int* ndim) {
+    if (!h || index < 0 || index >= (int)h->expected.size()) return fail(USE_E_INVALID, "bad index");
+    const Expected& e = h->expected[index];
+    if (name) *name = e.name.c_str();
+    if (ndim) *ndim = (int)e.shape.size();
+    if (shape4) for (size_t i = 0; i < 4; ++i) shape4[i] = i < e.shape.size() ? e.shape[i] : 1;
+    return USE_OK;
+}
+
+int use_set_weight(use_handle* h, const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!h || !name || !data || !shape) return fail(USE_E_INVALID, "null argument");
+    auto it = h->expected_index.find(name);
+    if (it == h->expected_index.end()) return fail(USE_E_INVALID, "unexpected weight name '%s'", name);
+    const Expected& e = h->expected[it->second];
+    if ((int)e.shape.size() != ndim) return fail(USE_E_INVALID, "weight '%s': rank %d, expected %zu", name, ndim, e.shape.size());
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] != e.shape[i]) return fail(USE_E_INVALID, "weight '%s': dim %d is %lld, expected %lld", name, i, (long long)shape[i], (long long)e.shape[i]);
+        n *= (size_t)shape[i];
+    }
+    h->host_w[name].assign(data, data + n);
+    h->weights_ready = false;
+    return USE_OK;
+}
+
+int use_alloc_weight_blob(use_handle* h) {
+    if (!h) return fail(USE_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->blob) HIPCHK(hipMalloc((void**)&h->blob, h->blob_bytes));
+    h->weights_ready = true;   // contents to be filled by the caller's broadcast
+    return USE_OK;
+}
+
+int use_commit_weights(use_handle* h) {
+    if (!h) return fail(USE_E_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<char> host(h->blob_bytes, 0);
+    int rc = pack_all(h, host.data());
+    if (rc) return rc;
+    if (!h->blob) HIPCHK(hipMalloc((void**)&h->blob, h->blob_bytes));
+    HIPCHK(hipMemcpy(h->blob, host.data(), h->blob_bytes, hipMemcpyHostToDevice));
+    h->host_w.clear();
+    h->weights_ready = true;
+    h->sampler_set = false;    // the temb table depends on the weights
+    drop_graphs(h);
+    return USE_OK;
+}
+
+int use_weight_blob(use_handle* h, void** dev_ptr, size_t* bytes) {
+    if (!h) return fail(USE_E_INVALID, "null handle");
+    if (dev_ptr) *dev_ptr = h->blob;
+    if (bytes) *bytes = h->blob_bytes;
+    return USE_OK;
+}
+
+int use_plan(use_handle* h, int B, int Tpad) {
+    if (!h) return fail(USE_E_INVALID, "null handle");
+    if (B < 1 || Tpad < 64 || Tpad % 64 != 0) return fail(USE_E_INVALID, "plan needs B >= 1 and T' a positive multiple of 64 (got B=%d T'=%d)", B, Tpad);
+    if ((Tpad >> (h->cfg.n_levels - 1)) < 1) return fail(USE_E_INVALID, "T' too small for %d levels", h->cfg.n_levels);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    drop_graphs(h);
+    h->B = B; h->T = Tpad; h->sampler_set = false;
+    // dry run to size the activation arena
+    if (h->arena.base) { HIPCHK(hipFree(h->arena.base)); h->arena.base = nullptr; }
+    h->arena.cap = 0; h->arena.peak = 0; h->dry = true;
+    { Fwd f{h, nullptr, nullptr, 0, nullptr, 0}; f.run(nullptr); }
+    h->dry = false;
+    h->arena.cap = h->arena.peak + 4096;
+    if (hipMalloc((void**)&h->arena.base, h->arena.cap) != hipSuccess)
+        return fail(USE_E_NOMEM, "cannot allocate %.1f MB of activation workspace", h->arena.cap / 1e6);
+    // persistent buffers
+    const size_t n = (size_t)B * h->cfg.n_freq * Tpad;
+    h->lang_blocks = (int)std::min<size_t>(256, ((size_t)h->cfg.n_freq * Tpad + 255) / 256);
+    if (h->persist) { HIPCHK(hipFree(h->persist)); h->persist = nullptr; }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; size_t o = off; off += bytes; return o; };
+    const size_t o_x4 = take(n * 16), o_Y = take(n * 8), o_X = take(n * 8), o_Xm = take(n * 8), o_sc = take(n * 8),
+                 o_xin = take(n * 8), o_st = take((size_t)B * 4 * h->cfg.nf * 4), o_tb = take((size_t)B * h->dense_rows * 4),
+                 o_t = take((size_t)B * 4), o_lp = take((size_t)B * h->lang_blocks * 2 * 4), o_ls = take(256), o_rng = take(256);
+    h->persist_bytes = off;
+    if (hipMalloc((void**)&h->persist, off) != hipSuccess) return fail(USE_E_NOMEM, "cannot allocate %.1f MB of state", off / 1e6);
+    h->x4 = (float*)(h->persist + o_x4); h->Y = (float2*)(h->persist + o_Y); h->X = (float2*)(h->persist + o_X);
+    h->Xmean = (float2*)(h->persist + o_Xm); h->score = (float2*)(h->persist + o_sc); h->xin = (float2*)(h->persist + o_xin);
+    h->silu_temb = (float*)(h->persist + o_st); h->tembias = (float*)(h->persist + o_tb); h->t_dev = (float*)(h->persist + o_t);
+    h->lang_partial = (float*)(h->persist + o_lp); h->lang_step = (float*)(h->persist + o_ls);
+    h->rng_state = (unsigned long long*)(h->persist + o_rng);
+    HIPCHK(hipMemset(h->persist, 0, off));
+    return USE_OK;
+}
+
+int use_workspace_bytes(use_handle* h, size_t* bytes) {
+    if (!h || !bytes) return fail(USE_E_INVALID, "null argument");
+    *bytes = h->arena.cap + h->persist_bytes + h->blob_bytes;
+    return USE_OK;
+}
+
+double use_flops_per_score(use_handle* h) { return h ? h->flops : 0.0; }
+
+static int check_ready(use_handle* h) {
+    if (!h) return fail(USE_E_INVALID, "null handle");
+    if (!h->weights_ready) return fail(USE_E_STATE, "weights not committed (use_commit_weights / use_alloc_weight_blob)");
+    if (!h->B) return fail(USE_E_STATE, "use_plan has not been called");
+    return USE_OK;
+}
+
+int use_score(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!x || !y || !t || !out) return fail(USE_E_INVALID, "null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    run_temb(h, t, h->B, h->silu_temb, h->tembias, s);
+    run_score(h, (const float2*)x, (const float2*)y, h->tembias, h->dense_rows, t, 1, (float2*)out, s);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+
+int use_set_sampler(use_handle* h, const use_sampler_config* sc) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!sc || sc->N < 1) return fail(USE_E_INVALID, "sampler needs N >= 1");
+    if (sc->predictor < 0 || sc->predictor > 2 || sc->corrector < 0 || sc->corrector > 2) return fail(USE_E_INVALID, "unknown predictor/corrector id");
+    if (sc->corrector != USE_CORR_NONE && sc->corrector_steps < 0) return fail(USE_E_INVALID, "negative corrector_steps");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    drop_graphs(h);
+    h->sc = *sc;
+    linspace_f32(1.0f, sc->t_eps, sc->N, h->timesteps);         // sampling/__init__.py:63 (sde.T == 1)
+    if (h->temb_table) { HIPCHK(hipFree(h->temb_table)); h->temb_table = nullptr; }
+    if (h->silu_table) { HIPCHK(hipFree(h->silu_table)); h->silu_table = nullptr; }
+    if (h->ts_dev) { HIPCHK(hipFree(h->ts_dev)); h->ts_dev = nullptr; }
+    HIPCHK(hipMalloc((void**)&h->temb_table, (size_t)sc->N * h->dense_rows * 4));
+    HIPCHK(hipMalloc((void**)&h->silu_table, (size_t)sc->N * 4 * h->cfg.nf * 4));
+    HIPCHK(hipMalloc((void**)&h->ts_dev, (size_t)sc->N * 4));
+    HIPCHK(hipMemcpy(h->ts_dev, h->timesteps.data(), (size_t)sc->N * 4, hipMemcpyHostToDevice));
+    run_temb(h, h->ts_dev, sc->N, h->silu_table, h->temb_table, nullptr);   // t is batch-uniform and known up front
+    HIPCHK(hipDeviceSynchronize());
+    h->sampler_set = true;
+    return USE_OK;
+}
+
+int use_num_noise_draws(use_handle* h) {
+    if (!h || !h->sampler_set) return fail(USE_E_STATE, "sampler not configured");
+    const int ncorr = h->sc.corrector == USE_CORR_NONE ? 0 : h->sc.corrector_steps;
+    return 1 + h->sc.N * (ncorr + (h->sc.predictor == USE_PRED_NONE ? 0 : 1));
+}
+
+int use_get_timesteps(use_handle* h, float* out, int n) {
+    if (!h || !h->sampler_set || !out) return fail(USE_E_STATE, "sampler not configured");
+    for (int i = 0; i < n && i < (int)h->timesteps.size(); ++i) out[i] = h->timesteps[i];
+    return (int)h->timesteps.size();
+}
+
+int use_sample(use_handle* h, const void* y, const void* noise, uint64_t seed, void* out, use_stream_t stream) {
+    int rc = check_ready(h); if (rc) return rc;
+    if (!h->sampler_set) return fail(USE_E_STATE, "use_set_sampler has not been called");
+    if (!y || !out) return fail(USE_E_INVALID, "null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)h->B * h->cfg.n_freq * h->T;
+    HIPCHK(hipMemcpyAsync(h->Y, y, n * 8, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(set_rng_kernel, dim3(1), dim3(1), 0, s, h->rng_state, (unsigned long long)seed, 0ull);
+    if (!h->sc.use_graph) {
+        run_sampler(h, (const float2*)noise, s);
+    } else {
+        const int gi = noise ? 1 : 0;
+        const float2* nz = nullptr;
+        if (noise) {
+            const size_t nb = (size_t)use_num_noise_draws(h) * n * 8;
+            if (nb > h->noise_copy_bytes) {
+                HIPCHK(hipStreamSynchronize(s));
+                if (h->noise_copy) HIPCHK(hipFree(h->noise_copy));
+                h->noise_copy = nullptr; h->noise_copy_bytes = 0;
+                if (h->graph_exec[1]) { (void)hipGraphExecDestroy(h->graph_exec[1]); h->graph_exec[1] = nullptr; }
+                if (hipMalloc((void**)&h->noise_copy, nb) != hipSuccess) return fail(USE_E_NOMEM, "cannot allocate %.1f MB noise staging", nb / 1e6);
+                h->noise_copy_bytes = nb;
+            }
+            HIPCHK(hipMemcpyAsync(h->noise_copy, noise, nb, hipMemcpyDeviceToDevice, s));
+            nz = h->noise_copy;
+        }
+        if (!h->graph_exec[gi]) {
+            rc = ensure_cap_stream(h); if (rc) return rc;
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+            run_sampler(h, nz, h->cap_stream);
+            HIPCHK(hipStreamEndCapture(h->cap_stream, &g));
+            hipError_t e = hipGraphInstantiate(&h->graph_exec[gi], g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) return fail(USE_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        }
+        HIPCHK(hipGraphLaunch(h->graph_exec[gi], s));
+    }
+    HIPCHK(hipMemcpyAsync(out, h->Xmean, n * 8, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+
+int use_sde_prior(use_handle* h, const void* y, const void* noise, uint64_t seed, void* x, int64_t n, use_stream_t s) {
+    int rc = ensure_sde_scratch(h); if (rc) return rc;
+    hipLaunchKernelGGL(set_rng_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, h->sde_rng, (unsigned long long)seed, 0ull);
+    launch_prior((const float2*)y, (const float2*)noise, RngRef{h->sde_rng, 0}, ouve_std(h->cfg, 1.0f), (float2*)x, n, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+
+int use_sde_predictor(use_handle* h, int predictor, float t, int N, const void* x, const void* y, const void* score,
+                      const void* noise, uint64_t seed, void* x_out, void* x_mean, int64_t n, use_stream_t s) {
+    int rc = ensure_sde_scratch(h); if (rc) return rc;
+    if (predictor != USE_PRED_REVERSE_DIFFUSION && predictor != USE_PRED_EULER_MARUYAMA) return fail(USE_E_INVALID, "predictor id %d has no update kernel", predictor);
+    float cd, cs, cn; predictor_coeffs(h->cfg, predictor, t, N, cd, cs, cn);
+    hipLaunchKernelGGL(set_rng_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, h->sde_rng, (unsigned long long)seed, 0ull);
+    launch_predictor((const float2*)x, (const float2*)y, (const float2*)score, (const float2*)noise, RngRef{h->sde_rng, 0},
+                     cd, cs, cn, (float2*)x_out, (float2*)x_mean, n, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+
+int use_sde_corrector(use_handle* h, int corrector, float t, float snr, int B, const void* x, const void* score,
+                      const void* noise, uint64_t seed, void* x_out, void* x_mean, int64_t n, use_stream_t st) {
+    int rc = ensure_sde_scratch(h); if (rc) return rc;
+    hipStream_t s = (hipStream_t)st;
+    if (B < 1 || n % B != 0) return fail(USE_E_INVALID, "n must be a multiple of B");
+    hipLaunchKernelGGL(set_rng_kernel, dim3(1), dim3(1), 0, s, h->sde_rng, (unsigned long long)seed, 0ull);
+    RngRef rr{h->sde_rng, 0};
+    if (corrector == USE_CORR_LANGEVIN) {
+        if (B > use_handle::SDE_MAX_B) return fail(USE_E_INVALID, "B=%d exceeds %d", B, use_handle::SDE_MAX_B);
+        launch_langevin_norms((const float2*)score, (const float2*)noise, rr, h->sde_partial, B, n / B, use_handle::SDE_BLOCKS, s);
+        launch_langevin_step(h->sde_partial, B, use_handle::SDE_BLOCKS, snr, h->sde_step, s);
+        launch_corrector((const float2*)x, (const float2*)score, (const float2*)noise, rr, h->sde_step, 0.f, (float2*)x_out, (float2*)x_mean, n, s);
+    } else if (corrector == USE_CORR_ALD) {
+        const float sd = snr * ouve_std(h->cfg, t);
+        launch_corrector((const float2*)x, (const float2*)score, (const float2*)noise, rr, nullptr, sd * sd * 2.f, (float2*)x_out, (float2*)x_mean, n, s);
+    } else return fail(USE_E_INVALID, "corrector id %d has no update kernel", corrector);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+
+int use_debug_tensor(use_handle* h, const char* name, void** dev_ptr, int* dims4, int* dtype) {
+    if (!h || !name) return fail(USE_E_INVALID, "null argument");
+    auto it = h->debug.find(name);
+    if (it == h->debug.end()) return fail(USE_E_INVALID, "no debug tensor '%s'", name);
+    if (dev_ptr) *dev_ptr = it->second.p;
+    if (dims4) { dims4[0] = h->B; dims4[1] = it->second.H; dims4[2] = it->second.W; dims4[3] = it->second.C; }
+    if (dtype) *dtype = it->second.dtype;
+    return USE_OK;
+}
+
+}  // extern "C"

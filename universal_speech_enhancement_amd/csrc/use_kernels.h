@@ -1,0 +1,90 @@
+// Launch wrappers for the gfx950 kernels of the SGMSE sampling path (internal C++ interface between
+// use_engine.cpp and use_kernels.hip).  All tensors are NHWC: [B][H=freq][W=frame][C], C contiguous.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace use {
+
+enum DType { DT_F32 = 0, DT_BF16 = 1 };
+inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+constexpr int TILE_H = 8;    // conv output tile: 8 x 16 pixels = 128 GEMM rows
+constexpr int TILE_W = 16;
+
+inline int tiles_per_image(int H, int W) { return ((H + TILE_H - 1) / TILE_H) * ((W + TILE_W - 1) / TILE_W); }
+
+// Implicit-GEMM convolution (3x3 pad 1, or 1x1) with fused prologue / epilogue.
+//   in   = concat(src0[C0], src1[C1]) along channels, optional per-(b, channel) affine
+//          (GroupNorm folded to a*x+b) followed by optional SiLU, zero outside the image
+//   out  = ((conv(in) + bias + temb[b]) + res) * out_scale + (w4 . pyr + b4)
+//   stats[b][tile][cout][2] = per-tile per-channel (sum, sum of squares) of the stored values
+struct ConvArgs {
+    const void* src0; const void* src1; int C0; int C1; int in_dtype;
+    const float* coef;      // [B][C0+C1][2] (a, b) or null
+    int act;                // 0: none, 1: SiLU (after the affine)
+    const void* w;          // packed [ntaps][CoutPad][C0+C1] in in_dtype
+    int cout_pad;
+    const float* bias;      // [Cout] or null
+    const float* temb;      // [B or 1][temb_stride] slice start for this conv, or null
+    int temb_bstride;       // elements between batch rows (0: shared by the batch)
+    const void* res;        // residual, out_dtype, [B,H,W,Cout] or null
+    float out_scale;
+    const float* pyr;       // fp32 [B,H,W,4] or null  (Combine 'sum' fused: + conv1x1_{4->Cout}(pyr))
+    const float* w4;        // [Cout][4]
+    const float* b4;        // [Cout]
+    void* out; int out_dtype;
+    float* stats;           // or null
+    int B, H, W, Cout, ntaps;
+};
+void launch_conv(const ConvArgs& a, hipStream_t s);
+
+// GroupNorm finalisation: per-(b, group) mean / rstd from per-tile per-channel partial sums of up to
+// two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b):  y = a*x + b.
+void launch_gn_finalize(const float* st0, int C0, const float* st1, int C1, int ntiles, const float* gamma,
+                        const float* beta, int groups, int hw, float eps, float* coef, int B, hipStream_t s);
+
+// FIR x2 resampling with the separable [1,3,3,1] kernel (upfirdn2d semantics of the reference).
+// out_act (nullable) = FIR(act(a*x+b)), out_raw (nullable) = FIR(x).
+void launch_fir_up2(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
+                    int H, int W, int C, hipStream_t s);
+void launch_fir_down2(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
+                      int H, int W, int C, hipStream_t s);
+
+// x4[b,f,t,:] = 2*(x.re, x.im, y.re, y.im) - 1   (fp32), x/y complex64 [B,F,T]
+void launch_pack_input(const float2* x, const float2* y, float* x4, long npix, hipStream_t s);
+
+// Time embedding: t[B] -> silu(Linear2(silu(Linear1(fourier(log t)))))  [B][4nf]
+void launch_temb_mlp(const float* t, int t_stride, const float* gfp_w, const float* w1, const float* b1,
+                     const float* w2, const float* b2, float* out_silu, int B, int nf, hipStream_t s);
+// All res-block Dense_0 layers at once: out[b][r] = bias[r] + dot(W[r], silu_temb[b])
+void launch_temb_dense(const float* silu_temb, const float* W, const float* bias, float* out, int B, int rows,
+                       int dim, hipStream_t s);
+
+// Bottleneck self-attention core: h[b,i,:] = sum_j softmax_j(q_i.k_j / sqrt(C)) v[b,j,:]
+void launch_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int N, int C,
+                      hipStream_t s);
+
+// net = conv1x1_{4->2}(pyr / t[b]); score = -net  (complex64 out)
+void launch_score_out(const float* pyr, const float* t, int t_stride, const float* w, const float* bias,
+                      float2* score, int B, long pix_per_b, hipStream_t s);
+
+// ---- SDE updates (complex64 as float2, fp32 arithmetic) ----
+struct RngRef { const unsigned long long* state; unsigned draw; };  // state[0]=seed, state[1]=draw base
+// z source: noise != null -> read noise[i]; else Philox(seed, draw)
+void launch_prior(const float2* y, const float2* noise, RngRef rng, float std1, float2* x, long n, hipStream_t s);
+// reverse-diffusion / Euler-Maruyama predictor: x_mean = x + c_drift*(y-x) + c_score*score ; x' = x_mean + c_noise*z
+void launch_predictor(const float2* x, const float2* y, const float2* score, const float2* noise, RngRef rng,
+                      float c_drift, float c_score, float c_noise, float2* x_out, float2* x_mean, long n,
+                      hipStream_t s);
+// Langevin norms: partial[b][blk] = (sum|g|^2, sum|z|^2)
+void launch_langevin_norms(const float2* score, const float2* noise, RngRef rng, float* partial, int B,
+                           long n_per_b, int blocks_per_b, hipStream_t s);
+// step[0] = 2*(snr * mean_b||z_b|| / mean_b||g_b||)^2
+void launch_langevin_step(const float* partial, int B, int blocks_per_b, float snr, float* step, hipStream_t s);
+// x_mean = x + eps*g ; x' = x_mean + sqrt(2 eps) z ; eps = step_dev[0] if step_dev else step_host
+void launch_corrector(const float2* x, const float2* score, const float2* noise, RngRef rng, const float* step_dev,
+                      float step_host, float2* x_out, float2* x_mean, long n, hipStream_t s);
+void launch_fill_noise(float2* out, RngRef rng, long n, hipStream_t s);
+
+}  // namespace use

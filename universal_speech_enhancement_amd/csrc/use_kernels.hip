@@ -1,0 +1,740 @@
+// gfx950 (CDNA4 / MI355X) kernels for the SGMSE reverse-SDE sampling path.
+//
+// What each kernel replaces in the reference (paths under src/models/components/sgmse/):
+//   conv_kernel        nn.Conv2d 3x3 / 1x1 (backbones/ncsnpp_utils/layers.py:113-162) with the GroupNorm-apply +
+//                      SiLU of its input (layerspp.py:283,304), bias, Dense_0(temb) bias (layerspp.py:302-303),
+//                      residual + 1/sqrt(2) (layerspp.py:311-314), Combine 'sum' (layerspp.py:50-55) and the
+//                      GroupNorm statistics of its output all fused in
+//   gn_finalize_kernel nn.GroupNorm statistics (min(C//4,32) groups, eps 1e-6), folded to a per-channel affine
+//   fir_*_kernel       upsample_2d / downsample_2d (up_or_down_sampling.py:202-264; CUDA: op/upfirdn2d_kernel.cu)
+//   attention_kernel   AttnBlockpp einsum / softmax / einsum (layerspp.py:84-88)
+//   temb_*             GaussianFourierProjection + 2 Linear (layerspp.py:37-39, ncsnpp.py:352-368), Dense_0
+//   score_out / prior / predictor / langevin_* / corrector
+//                      ncsnpp.py:492-500, model_wrapper.py:137, sdes.py:248-254, sampling/predictors.py:40-68,
+//                      sampling/correctors.py:45-98
+//
+// Layout: activations are NHWC ([B][freq][frame][C]); a conv is an implicit GEMM with M = pixels (8x16 tiles),
+// N = output channels, K = taps x input channels, computed with 32x32 MFMA tiles (bf16: v_mfma_f32_32x32x16_bf16,
+// fp32 parity mode: v_mfma_f32_32x32x2_f32), fp32 accumulation.  The input halo tile (10x18 pixels x CK channels)
+// is staged in LDS once per channel chunk and re-used by the 9 taps; weights stream through a double-buffered
+// LDS slab.  Wave = 64 lanes everywhere.
+#include "use_kernels.h"
+
+#include <math.h>
+
+namespace use {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define DEVI __device__ __forceinline__
+
+template <bool ACCURATE>
+DEVI float silu_f(float x) {
+    if (ACCURATE) return x / (1.0f + expf(-x));
+    return x * __frcp_rn(1.0f + __expf(-x));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 16-byte vector <-> float helpers
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    DEVI static void load(const float* p, float (&v)[4]) {
+        float4 u = *reinterpret_cast<const float4*>(p);
+        v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+    }
+    DEVI static uint4 pack(const float (&v)[4]) {
+        float4 u = make_float4(v[0], v[1], v[2], v[3]);
+        return __builtin_bit_cast(uint4, u);
+    }
+    DEVI static void store(float* p, const float (&v)[4]) { *reinterpret_cast<uint4*>(p) = pack(v); }
+};
+template <> struct Vec16<__bf16> {
+    static constexpr int N = 8;
+    DEVI static void load(const __bf16* p, float (&v)[8]) {
+        uint4 u = *reinterpret_cast<const uint4*>(p);
+        bf16x8 b = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)b[i];
+    }
+    DEVI static uint4 pack(const float (&v)[8]) {
+        bf16x8 b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = (__bf16)v[i];
+        return __builtin_bit_cast(uint4, b);
+    }
+    DEVI static void store(__bf16* p, const float (&v)[8]) { *reinterpret_cast<uint4*>(p) = pack(v); }
+};
+
+template <typename T> DEVI float to_f(T v) { return (float)v; }
+template <typename T> DEVI T from_f(float v) { return (T)v; }
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA traits: one 32x32 output tile per instruction; lanes 0-31 carry the first half of the K slab and lanes
+// 32-63 the second half, KPL contiguous k per lane (cdna_hip_programming.md section 3).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> struct Mfma;
+template <> struct Mfma<__bf16> {
+    static constexpr int KM = 16, KPL = 8;
+    typedef bf16x8 frag;
+    DEVI static frag ld(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+    DEVI static f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma<float> {
+    static constexpr int KM = 2, KPL = 1;
+    typedef float frag;
+    DEVI static frag ld(const char* p) { return *reinterpret_cast<const float*>(p); }
+    DEVI static f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution
+// ---------------------------------------------------------------------------------------------------------
+constexpr int BM = TILE_H * TILE_W;     // 128 pixels
+constexpr int HALO_MAX = (TILE_H + 2) * (TILE_W + 2);
+
+template <typename TIN, typename TOUT, int CK, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
+    typedef Mfma<TIN> MF;
+    constexpr int VEC = 16 / sizeof(TIN);
+    constexpr int PARTS = CK / VEC;                       // 16-byte pieces per pixel row of a chunk
+    constexpr int ROWB = CK * (int)sizeof(TIN) + 16;      // padded LDS row (bytes)
+    constexpr int MW = BM / WM, NW = BN / WN;             // wave tile
+    constexpr int TM = MW / 32, TN = NW / 32;
+    constexpr int KSTEPS = CK / MF::KM;
+    constexpr int WPT = (BN * PARTS + 255) / 256;         // 16-byte weight pieces per thread per (tap, chunk)
+    constexpr bool WGUARD = (BN * PARTS) % 256 != 0;
+    constexpr bool ACC = sizeof(TIN) == 4;                // fp32 parity mode: accurate SiLU
+    static_assert(WM * WN == 4 && MW % 32 == 0 && NW % 32 == 0 && CK % MF::KM == 0 && PARTS >= 1, "tiling");
+
+    __shared__ __attribute__((aligned(16))) char s_halo[HALO_MAX * ROWB];
+    __shared__ __attribute__((aligned(16))) char s_w[2][BN * ROWB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int b = blockIdx.z;
+    const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
+    const int ty0 = (blockIdx.x / tiles_x) * TILE_H, tx0 = (blockIdx.x % tiles_x) * TILE_W;
+    const int n0 = blockIdx.y * BN;
+    const int pad = (p.ntaps == 9) ? 1 : 0;
+    const int HW_ = TILE_W + 2 * pad, HH_ = TILE_H + 2 * pad;
+    const int Ctot = p.C0 + p.C1;
+    const int nchunks = Ctot / CK;
+    const int nit = nchunks * p.ntaps;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // per-lane fragment bases (bytes)
+    int a_base[TM], b_base[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int m = wm * MW + i * 32 + (lane & 31);
+        a_base[i] = ((m >> 4) * HW_ + (m & 15)) * ROWB + (lane >> 5) * MF::KPL * (int)sizeof(TIN);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        b_base[j] = (wn * NW + j * 32 + (lane & 31)) * ROWB + (lane >> 5) * MF::KPL * (int)sizeof(TIN);
+
+    auto stage_halo = [&](int chunk) {
+        const int c_glob = chunk * CK;
+        const TIN* src; int Cs, c_loc;
+        if (c_glob < p.C0) { src = (const TIN*)p.src0; Cs = p.C0; c_loc = c_glob; }
+        else               { src = (const TIN*)p.src1; Cs = p.C1; c_loc = c_glob - p.C0; }
+        const int part = tid % PARTS;                      // constant per thread (256 % PARTS == 0)
+        float ca[VEC], cb[VEC];
+        if (p.coef) {
+            const float* cf = p.coef + ((size_t)b * Ctot + c_glob + part * VEC) * 2;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { ca[k] = cf[2 * k]; cb[k] = cf[2 * k + 1]; }
+        }
+        const int npix = HW_ * HH_;
+        for (int idx = tid; idx < npix * PARTS; idx += 256) {
+            const int pix = idx / PARTS;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            const int gy = ty0 + hy - pad, gx = tx0 + hx - pad;
+            float v[VEC];
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                Vec16<TIN>::load(src + ((size_t)(b * p.H + gy) * p.W + gx) * Cs + c_loc + part * VEC, v);
+                if (p.coef) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) v[k] = fmaf(v[k], ca[k], cb[k]);
+                }
+                if (p.act) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) v[k] = silu_f<ACC>(v[k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v[k] = 0.f;
+            }
+            *reinterpret_cast<uint4*>(s_halo + pix * ROWB + part * 16) = Vec16<TIN>::pack(v);
+        }
+    };
+
+    static_assert(WPT <= 4, "weight staging registers");
+    uint4 wr0 = make_uint4(0, 0, 0, 0), wr1 = wr0, wr2 = wr0, wr3 = wr0;   // named (an array gets demoted to LDS)
+#define USE_LOAD_Q(Q, DST)                                                                                     \
+    if (WPT > (Q)) {                                                                                           \
+        const int idx = tid + (Q)*256;                                                                         \
+        if (!WGUARD || idx < BN * PARTS)                                                                       \
+            DST = *reinterpret_cast<const uint4*>(wb_ + (size_t)(idx / PARTS) * Ctot + (idx % PARTS) * VEC);   \
+    }
+#define USE_LOAD_W(IT)                                                                                         \
+    {                                                                                                          \
+        const int chunk_ = (IT) / p.ntaps, tap_ = (IT)-chunk_ * p.ntaps;                                       \
+        const TIN* wb_ = (const TIN*)p.w + ((size_t)tap_ * p.cout_pad + n0) * Ctot + chunk_ * CK;             \
+        USE_LOAD_Q(0, wr0) USE_LOAD_Q(1, wr1) USE_LOAD_Q(2, wr2) USE_LOAD_Q(3, wr3)                            \
+    }
+#define USE_STORE_Q(Q, SRC, BUF)                                                                               \
+    if (WPT > (Q)) {                                                                                           \
+        const int idx = tid + (Q)*256;                                                                         \
+        if (!WGUARD || idx < BN * PARTS)                                                                       \
+            *reinterpret_cast<uint4*>(s_w[BUF] + (idx / PARTS) * ROWB + (idx % PARTS) * 16) = SRC;             \
+    }
+#define USE_STORE_W(BUF)                                                                                       \
+    { USE_STORE_Q(0, wr0, BUF) USE_STORE_Q(1, wr1, BUF) USE_STORE_Q(2, wr2, BUF) USE_STORE_Q(3, wr3, BUF) }
+
+    stage_halo(0);
+    USE_LOAD_W(0);
+    USE_STORE_W(0);
+    __syncthreads();
+
+    for (int it = 0; it < nit; ++it) {
+        const int chunk = it / p.ntaps, tap = it - chunk * p.ntaps;
+        const bool has_next = (it + 1 < nit);
+        if (has_next) USE_LOAD_W(it + 1);
+        const int dy = pad ? tap / 3 : 0, dx = pad ? tap - dy * 3 : 0;
+        const char* ha = s_halo + (dy * HW_ + dx) * ROWB;
+        const char* wb = s_w[it & 1];
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            typename MF::frag af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = MF::ld(ha + a_base[i] + kk * MF::KM * (int)sizeof(TIN));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = MF::ld(wb + b_base[j] + kk * MF::KM * (int)sizeof(TIN));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[i], bf[j], acc[i][j]);
+        }
+        if (has_next) {
+            USE_STORE_W((it + 1) & 1);
+            if (tap == p.ntaps - 1) {          // next iteration starts a new channel chunk: restage the halo
+                __syncthreads();
+                stage_halo(chunk + 1);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------ epilogue ------------------------------
+    float st_s[TN], st_q[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
+    TOUT* out = (TOUT*)p.out;
+    const TOUT* res = (const TOUT*)p.res;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn * NW + j * 32 + (lane & 31);
+        const bool cok = co < p.Cout;
+        float add = 0.f;
+        float w4v[4] = {0.f, 0.f, 0.f, 0.f}; float b4v = 0.f;
+        if (cok) {
+            if (p.bias) add += p.bias[co];
+            if (p.temb) add += p.temb[(size_t)b * p.temb_bstride + co];
+            if (p.pyr) {
+                const float4 wq = *reinterpret_cast<const float4*>(p.w4 + (size_t)co * 4);
+                w4v[0] = wq.x; w4v[1] = wq.y; w4v[2] = wq.z; w4v[3] = wq.w; b4v = p.b4[co];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = wm * MW + i * 32 + row;
+                const int gy = ty0 + (m >> 4), gx = tx0 + (m & 15);
+                if (cok && gy < p.H && gx < p.W) {
+                    const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+                    float v = acc[i][j][r] + add;
+                    if (res) v += to_f(res[pix * p.Cout + co]);
+                    v *= p.out_scale;
+                    if (p.pyr) {
+                        const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
+                        v += b4v + w4v[0] * pq.x + w4v[1] * pq.y + w4v[2] * pq.z + w4v[3] * pq.w;
+                    }
+                    const TOUT o = from_f<TOUT>(v);
+                    out[pix * p.Cout + co] = o;
+                    const float vr = to_f(o);
+                    st_s[j] += vr; st_q[j] += vr * vr;
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        float* red = reinterpret_cast<float*>(s_halo);     // [WM][BN][2]; all LDS reads finished (loop-end sync)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = st_s[j] + __shfl_xor(st_s[j], 32);
+            float q = st_q[j] + __shfl_xor(st_q[j], 32);
+            if (lane < 32) {
+                const int cl = wn * NW + j * 32 + lane;
+                red[(wm * BN + cl) * 2] = s; red[(wm * BN + cl) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+            const int co = n0 + tid;
+            if (co < p.Cout) {
+                float* dst = p.stats + (((size_t)b * gridDim.x + blockIdx.x) * p.Cout + co) * 2;
+                dst[0] = s; dst[1] = q;
+            }
+        }
+    }
+}
+
+template <typename TIN, typename TOUT, int CK, int BN, int WM, int WN>
+static void conv_launch_t(const ConvArgs& a, hipStream_t s) {
+    dim3 grid(tiles_per_image(a.H, a.W), (a.Cout + BN - 1) / BN, a.B);
+    hipLaunchKernelGGL((conv_kernel<TIN, TOUT, CK, BN, WM, WN>), grid, dim3(256), 0, s, a);
+}
+
+void launch_conv(const ConvArgs& a, hipStream_t s) {
+    const int Ctot = a.C0 + a.C1;
+    const bool small_n = a.Cout <= 32;
+    if (a.in_dtype == DT_BF16) {
+        // bf16 activations: 64-channel chunks
+        if (a.out_dtype == DT_BF16) { small_n ? conv_launch_t<__bf16, __bf16, 64, 32, 4, 1>(a, s) : conv_launch_t<__bf16, __bf16, 64, 128, 2, 2>(a, s); }
+        else                        { small_n ? conv_launch_t<__bf16, float, 64, 32, 4, 1>(a, s) : conv_launch_t<__bf16, float, 64, 128, 2, 2>(a, s); }
+    } else {
+        if (Ctot % 32 == 0) {
+            if (a.out_dtype == DT_BF16) { small_n ? conv_launch_t<float, __bf16, 32, 32, 4, 1>(a, s) : conv_launch_t<float, __bf16, 32, 128, 2, 2>(a, s); }
+            else                        { small_n ? conv_launch_t<float, float, 32, 32, 4, 1>(a, s) : conv_launch_t<float, float, 32, 128, 2, 2>(a, s); }
+        } else {  // Cin = 4 (network input): one 4-channel chunk per tap
+            if (a.out_dtype == DT_BF16) conv_launch_t<float, __bf16, 4, 128, 2, 2>(a, s);
+            else                        conv_launch_t<float, float, 4, 128, 2, 2>(a, s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GroupNorm finalize: one block per (group, batch item)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ st0, int C0,
+                                                          const float* __restrict__ st1, int C1, int ntiles,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int groups, int hw,
+                                                          float eps, float* __restrict__ coef) {
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int C = C0 + C1, cpg = C / groups;
+    double s = 0.0, q = 0.0;
+    for (int idx = threadIdx.x; idx < ntiles * cpg; idx += 256) {
+        const int tile = idx / cpg, c = g * cpg + (idx - tile * cpg);
+        const float* p = (c < C0) ? st0 + (((size_t)b * ntiles + tile) * C0 + c) * 2
+                                  : st1 + (((size_t)b * ntiles + tile) * C1 + (c - C0)) * 2;
+        s += (double)p[0]; q += (double)p[1];
+    }
+    __shared__ double rs[4], rq[4];
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rq[threadIdx.x >> 6] = q; }
+    __syncthreads();
+    s = rs[0] + rs[1] + rs[2] + rs[3];
+    q = rq[0] + rq[1] + rq[2] + rq[3];
+    const double n = (double)cpg * (double)hw;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x < cpg) {
+        const int c = g * cpg + threadIdx.x;
+        const float a = gamma[c] * rstd;
+        coef[((size_t)b * C + c) * 2] = a;
+        coef[((size_t)b * C + c) * 2 + 1] = beta[c] - (float)mean * a;
+    }
+}
+
+void launch_gn_finalize(const float* st0, int C0, const float* st1, int C1, int ntiles, const float* gamma,
+                        const float* beta, int groups, int hw, float eps, float* coef, int B, hipStream_t s) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, st0, C0, st1, C1, ntiles, gamma, beta,
+                       groups, hw, eps, coef);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// FIR x2 resampling, separable [1,3,3,1]: up -> polyphase (0.25, 0.75) pairs; down -> [1,3,3,1]/8 per axis
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, bool UP>
+__global__ __launch_bounds__(256) void fir_kernel(const T* __restrict__ src, const float* __restrict__ coef, int act,
+                                                  T* __restrict__ out_act, T* __restrict__ out_raw, int B, int H,
+                                                  int W, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    constexpr bool ACC = sizeof(T) == 4;
+    const int cv = C / VEC;
+    const int OH = UP ? 2 * H : H / 2, OW = UP ? 2 * W : W / 2;
+    const long total = (long)B * OH * OW * cv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * VEC;
+        long pix = idx / cv;
+        const int ox = (int)(pix % OW); pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int b = (int)(pix / OH);
+        float ca[VEC], cb[VEC];
+        const bool want_act = out_act != nullptr;
+        if (want_act && coef) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { ca[k] = coef[((size_t)b * C + c + k) * 2]; cb[k] = coef[((size_t)b * C + c + k) * 2 + 1]; }
+        }
+        float ar[VEC], aa[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { ar[k] = 0.f; aa[k] = 0.f; }
+        constexpr int NT = UP ? 2 : 4;
+        int ys[NT], xs[NT]; float wy[NT], wx[NT];
+        if (UP) {
+            const int my = oy >> 1, mx = ox >> 1;
+            if (oy & 1) { ys[0] = my; wy[0] = 0.75f; ys[1] = my + 1; wy[1] = 0.25f; }
+            else        { ys[0] = my - 1; wy[0] = 0.25f; ys[1] = my; wy[1] = 0.75f; }
+            if (ox & 1) { xs[0] = mx; wx[0] = 0.75f; xs[1] = mx + 1; wx[1] = 0.25f; }
+            else        { xs[0] = mx - 1; wx[0] = 0.25f; xs[1] = mx; wx[1] = 0.75f; }
+        } else {
+            const float k4[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+#pragma unroll
+            for (int a = 0; a < NT; ++a) { ys[a] = 2 * oy - 1 + a; wy[a] = k4[a]; xs[a] = 2 * ox - 1 + a; wx[a] = k4[a]; }
+        }
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            if (ys[a] < 0 || ys[a] >= H) continue;
+#pragma unroll
+            for (int e = 0; e < NT; ++e) {
+                if (xs[e] < 0 || xs[e] >= W) continue;
+                const float wgt = wy[a] * wx[e];
+                float v[VEC];
+                Vec16<T>::load(src + ((size_t)(b * H + ys[a]) * W + xs[e]) * C + c, v);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    ar[k] = fmaf(wgt, v[k], ar[k]);
+                    if (want_act) {
+                        float u = coef ? fmaf(v[k], ca[k], cb[k]) : v[k];
+                        if (act) u = silu_f<ACC>(u);
+                        aa[k] = fmaf(wgt, u, aa[k]);
+                    }
+                }
+            }
+        }
+        const size_t o = ((size_t)(b * OH + oy) * OW + ox) * C + c;
+        if (out_raw) Vec16<T>::store(out_raw + o, ar);
+        if (want_act) Vec16<T>::store(out_act + o, aa);
+    }
+}
+
+template <bool UP>
+static void fir_launch(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
+                       int H, int W, int C, hipStream_t s) {
+    const int OH = UP ? 2 * H : H / 2, OW = UP ? 2 * W : W / 2;
+    const int vec = dtype == DT_F32 ? 4 : 8;
+    const long total = (long)B * OH * OW * (C / vec);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    if (dtype == DT_F32)
+        hipLaunchKernelGGL((fir_kernel<float, UP>), dim3(blocks), dim3(256), 0, s, (const float*)src, coef, act,
+                           (float*)out_act, (float*)out_raw, B, H, W, C);
+    else
+        hipLaunchKernelGGL((fir_kernel<__bf16, UP>), dim3(blocks), dim3(256), 0, s, (const __bf16*)src, coef, act,
+                           (__bf16*)out_act, (__bf16*)out_raw, B, H, W, C);
+}
+void launch_fir_up2(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
+                    int H, int W, int C, hipStream_t s) { fir_launch<true>(src, dtype, coef, act, out_act, out_raw, B, H, W, C, s); }
+void launch_fir_down2(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
+                      int H, int W, int C, hipStream_t s) { fir_launch<false>(src, dtype, coef, act, out_act, out_raw, B, H, W, C, s); }
+
+// ---------------------------------------------------------------------------------------------------------
+// Input packing
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_input_kernel(const float2* __restrict__ x, const float2* __restrict__ y,
+                                                         float4* __restrict__ x4, long npix) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+        const float2 a = x[i], c = y[i];
+        x4[i] = make_float4(2.f * a.x - 1.f, 2.f * a.y - 1.f, 2.f * c.x - 1.f, 2.f * c.y - 1.f);
+    }
+}
+static int ew_blocks(long n) { long b = (n + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
+void launch_pack_input(const float2* x, const float2* y, float* x4, long npix, hipStream_t s) {
+    hipLaunchKernelGGL(pack_input_kernel, dim3(ew_blocks(npix)), dim3(256), 0, s, x, y, (float4*)x4, npix);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Time embedding
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void temb_mlp_kernel(const float* __restrict__ t, int t_stride,
+                                                       const float* __restrict__ gfp_w, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2,
+                                                       const float* __restrict__ b2, float* __restrict__ out, int nf) {
+    extern __shared__ float sm[];           // [2nf] fourier features, then [4nf] hidden
+    float* feat = sm; float* hid = sm + 2 * nf;
+    const int b = blockIdx.x, D = 4 * nf;
+    const float lt = logf(t[(size_t)b * t_stride]);
+    for (int i = threadIdx.x; i < nf; i += blockDim.x) {
+        const float xp = lt * gfp_w[i] * 2.f * 3.14159265358979323846f;
+        feat[i] = sinf(xp); feat[nf + i] = cosf(xp);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < D; o += blockDim.x) {
+        float a = b1[o];
+        const float* wr = w1 + (size_t)o * 2 * nf;
+        for (int k = 0; k < 2 * nf; ++k) a = fmaf(wr[k], feat[k], a);
+        hid[o] = silu_f<true>(a);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < D; o += blockDim.x) {
+        float a = b2[o];
+        const float* wr = w2 + (size_t)o * D;
+        for (int k = 0; k < D; ++k) a = fmaf(wr[k], hid[k], a);
+        out[(size_t)b * D + o] = silu_f<true>(a);     // res-blocks consume act(temb) (layerspp.py:303)
+    }
+}
+void launch_temb_mlp(const float* t, int t_stride, const float* gfp_w, const float* w1, const float* b1,
+                     const float* w2, const float* b2, float* out_silu, int B, int nf, hipStream_t s) {
+    hipLaunchKernelGGL(temb_mlp_kernel, dim3(B), dim3(512), 6 * nf * sizeof(float), s, t, t_stride, gfp_w, w1, b1, w2,
+                       b2, out_silu, nf);
+}
+
+__global__ __launch_bounds__(256) void temb_dense_kernel(const float* __restrict__ st, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         int rows, int dim) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* wr = W + (size_t)r * dim; const float* x = st + (size_t)b * dim;
+    float a = 0.f;
+    for (int k = lane; k < dim; k += 64) a = fmaf(wr[k], x[k], a);
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) out[(size_t)b * rows + r] = a + bias[r];
+}
+void launch_temb_dense(const float* silu_temb, const float* W, const float* bias, float* out, int B, int rows,
+                       int dim, hipStream_t s) {
+    hipLaunchKernelGGL(temb_dense_kernel, dim3((rows + 3) / 4, B), dim3(256), 0, s, silu_temb, W, bias, out, rows, dim);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Attention core: one block per (query token, batch item); fp32 arithmetic
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                        const T* __restrict__ v, T* __restrict__ out, int N, int C) {
+    extern __shared__ float sm[];            // [C] query, [N] scores
+    float* sq = sm; float* sc = sm + C;
+    __shared__ float red[4];
+    const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const T* qb = q + ((size_t)b * N + i) * C;
+    for (int c = tid; c < C; c += 256) sq[c] = to_f(qb[c]);
+    __syncthreads();
+    const float scale = rsqrtf((float)C);    // int(C) ** -0.5 (layerspp.py:84)
+    float mx = -INFINITY;
+    for (int j = tid; j < N; j += 256) {
+        const T* kb = k + ((size_t)b * N + j) * C;
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a = fmaf(sq[c], to_f(kb[c]), a);
+        a *= scale; sc[j] = a; mx = fmaxf(mx, a);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = tid; j < N; j += 256) { const float e = expf(sc[j] - mx); sc[j] = e; sum += e; }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.f;
+        for (int j = 0; j < N; ++j) a = fmaf(sc[j], to_f(v[((size_t)b * N + j) * C + c]), a);
+        out[((size_t)b * N + i) * C + c] = from_f<T>(a * inv);
+    }
+}
+void launch_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int N, int C,
+                      hipStream_t s) {
+    const size_t sh = (size_t)(C + N) * sizeof(float);
+    if (dtype == DT_F32)
+        hipLaunchKernelGGL((attention_kernel<float>), dim3(N, B), dim3(256), sh, s, (const float*)q, (const float*)k,
+                           (const float*)v, (float*)out, N, C);
+    else
+        hipLaunchKernelGGL((attention_kernel<__bf16>), dim3(N, B), dim3(256), sh, s, (const __bf16*)q,
+                           (const __bf16*)k, (const __bf16*)v, (__bf16*)out, N, C);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Output layer + SDE updates
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void score_out_kernel(const float4* __restrict__ pyr, const float* __restrict__ t,
+                                                        int t_stride, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float2* __restrict__ score,
+                                                        long pix_per_b) {
+    const int b = blockIdx.y;
+    const float tv = t[(size_t)b * t_stride];
+    const float w00 = w[0], w01 = w[1], w02 = w[2], w03 = w[3], w10 = w[4], w11 = w[5], w12 = w[6], w13 = w[7];
+    const float b0 = bias[0], b1 = bias[1];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pix_per_b; i += (long)gridDim.x * 256) {
+        float4 h = pyr[(size_t)b * pix_per_b + i];
+        h.x /= tv; h.y /= tv; h.z /= tv; h.w /= tv;              // h / used_sigmas (ncsnpp.py:492-494)
+        const float re = b0 + w00 * h.x + w01 * h.y + w02 * h.z + w03 * h.w;
+        const float im = b1 + w10 * h.x + w11 * h.y + w12 * h.z + w13 * h.w;
+        score[(size_t)b * pix_per_b + i] = make_float2(-re, -im);  // score = -score_net(...) (model_wrapper.py:137)
+    }
+}
+void launch_score_out(const float* pyr, const float* t, int t_stride, const float* w, const float* bias,
+                      float2* score, int B, long pix_per_b, hipStream_t s) {
+    int bx = (int)((pix_per_b + 255) / 256); if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(score_out_kernel, dim3(bx, B), dim3(256), 0, s, (const float4*)pyr, t, t_stride, w, bias, score,
+                       pix_per_b);
+}
+
+// Philox4x32-10 counter RNG -> complex normal with E|z|^2 = 1 (torch.randn_like(complex) law).
+DEVI void philox_round(unsigned (&c)[4], unsigned (&k)[2]) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k[0], n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k[1], n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+DEVI float2 philox_cnormal(unsigned long long seed, unsigned long long draw, unsigned long long idx) {
+    unsigned c[4] = {(unsigned)idx, (unsigned)(idx >> 32), (unsigned)draw, (unsigned)(draw >> 32)};
+    unsigned k[2] = {(unsigned)seed, (unsigned)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+    const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-logf(u1));           // sqrt(-2 ln u) * sqrt(1/2)
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    return make_float2(r * cs, r * sn);
+}
+DEVI float2 get_noise(const float2* noise, RngRef rng, long i) {
+    if (noise) return noise[i];
+    return philox_cnormal(rng.state[0], rng.state[1] + rng.draw, (unsigned long long)i);
+}
+
+__global__ __launch_bounds__(256) void fill_noise_kernel(float2* out, RngRef rng, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = get_noise(nullptr, rng, i);
+}
+void launch_fill_noise(float2* out, RngRef rng, long n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_noise_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, out, rng, n);
+}
+
+__global__ __launch_bounds__(256) void prior_kernel(const float2* __restrict__ y, const float2* __restrict__ noise,
+                                                    RngRef rng, float std1, float2* __restrict__ x, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float2 z = get_noise(noise, rng, i), yy = y[i];
+        x[i] = make_float2(yy.x + z.x * std1, yy.y + z.y * std1);     // sdes.py:254
+    }
+}
+void launch_prior(const float2* y, const float2* noise, RngRef rng, float std1, float2* x, long n, hipStream_t s) {
+    hipLaunchKernelGGL(prior_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, y, noise, rng, std1, x, n);
+}
+
+__global__ __launch_bounds__(256) void predictor_kernel(const float2* __restrict__ x, const float2* __restrict__ y,
+                                                        const float2* __restrict__ score,
+                                                        const float2* __restrict__ noise, RngRef rng, float c_drift,
+                                                        float c_score, float c_noise, float2* __restrict__ x_out,
+                                                        float2* __restrict__ x_mean, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float2 xv = x[i], yv = y[i], sv = score[i], z = get_noise(noise, rng, i);
+        // x_mean = x - [theta (y-x) dt - G^2 s]   (predictors.py:62-65, sdes.py:88-92,164-167)
+        const float fx = c_drift * (yv.x - xv.x) - c_score * sv.x;
+        const float fy = c_drift * (yv.y - xv.y) - c_score * sv.y;
+        const float mx = xv.x - fx, my = xv.y - fy;
+        if (x_mean) x_mean[i] = make_float2(mx, my);
+        x_out[i] = make_float2(mx + c_noise * z.x, my + c_noise * z.y);
+    }
+}
+void launch_predictor(const float2* x, const float2* y, const float2* score, const float2* noise, RngRef rng,
+                      float c_drift, float c_score, float c_noise, float2* x_out, float2* x_mean, long n,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(predictor_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, score, noise, rng, c_drift,
+                       c_score, c_noise, x_out, x_mean, n);
+}
+
+__global__ __launch_bounds__(256) void langevin_norms_kernel(const float2* __restrict__ score,
+                                                             const float2* __restrict__ noise, RngRef rng,
+                                                             float* __restrict__ partial, long n_per_b) {
+    const int b = blockIdx.y;
+    float g2 = 0.f, z2 = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_per_b; i += (long)gridDim.x * 256) {
+        const long gi = (long)b * n_per_b + i;
+        const float2 g = score[gi], z = get_noise(noise, rng, gi);
+        g2 += g.x * g.x + g.y * g.y; z2 += z.x * z.x + z.y * z.y;
+    }
+    __shared__ float rg[4], rz[4];
+    for (int o = 32; o > 0; o >>= 1) { g2 += __shfl_xor(g2, o); z2 += __shfl_xor(z2, o); }
+    if ((threadIdx.x & 63) == 0) { rg[threadIdx.x >> 6] = g2; rz[threadIdx.x >> 6] = z2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* dst = partial + ((size_t)b * gridDim.x + blockIdx.x) * 2;
+        dst[0] = rg[0] + rg[1] + rg[2] + rg[3]; dst[1] = rz[0] + rz[1] + rz[2] + rz[3];
+    }
+}
+void launch_langevin_norms(const float2* score, const float2* noise, RngRef rng, float* partial, int B,
+                           long n_per_b, int blocks_per_b, hipStream_t s) {
+    hipLaunchKernelGGL(langevin_norms_kernel, dim3(blocks_per_b, B), dim3(256), 0, s, score, noise, rng, partial,
+                       n_per_b);
+}
+
+__global__ __launch_bounds__(64) void langevin_step_kernel(const float* __restrict__ partial, int B, int blocks_per_b,
+                                                           float snr, float* __restrict__ step) {
+    // mean over the batch of per-item L2 norms (correctors.py:55-56), one wave
+    double gn = 0.0, zn = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double g2 = 0.0, z2 = 0.0;
+        for (int k = threadIdx.x; k < blocks_per_b; k += 64) {
+            g2 += (double)partial[((size_t)b * blocks_per_b + k) * 2];
+            z2 += (double)partial[((size_t)b * blocks_per_b + k) * 2 + 1];
+        }
+        for (int o = 32; o > 0; o >>= 1) { g2 += __shfl_xor(g2, o); z2 += __shfl_xor(z2, o); }
+        gn += sqrt(g2); zn += sqrt(z2);
+    }
+    if (threadIdx.x == 0) {
+        const float gm = (float)(gn / B), zm = (float)(zn / B);
+        const float r = snr * zm / gm;
+        step[0] = r * r * 2.f;                                   // correctors.py:57
+    }
+}
+void launch_langevin_step(const float* partial, int B, int blocks_per_b, float snr, float* step, hipStream_t s) {
+    hipLaunchKernelGGL(langevin_step_kernel, dim3(1), dim3(64), 0, s, partial, B, blocks_per_b, snr, step);
+}
+
+__global__ __launch_bounds__(256) void corrector_kernel(const float2* __restrict__ x, const float2* __restrict__ score,
+                                                        const float2* __restrict__ noise, RngRef rng,
+                                                        const float* __restrict__ step_dev, float step_host,
+                                                        float2* __restrict__ x_out, float2* __restrict__ x_mean,
+                                                        long n) {
+    const float eps = step_dev ? step_dev[0] : step_host;
+    const float sq = sqrtf(eps * 2.f);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float2 xv = x[i], g = score[i], z = get_noise(noise, rng, i);
+        const float mx = xv.x + eps * g.x, my = xv.y + eps * g.y;   // correctors.py:60-61
+        if (x_mean) x_mean[i] = make_float2(mx, my);
+        x_out[i] = make_float2(mx + z.x * sq, my + z.y * sq);
+    }
+}
+void launch_corrector(const float2* x, const float2* score, const float2* noise, RngRef rng, const float* step_dev,
+                      float step_host, float2* x_out, float2* x_mean, long n, hipStream_t s) {
+    hipLaunchKernelGGL(corrector_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, score, noise, rng, step_dev,
+                       step_host, x_out, x_mean, n);
+}
+
+}  // namespace use

@@ -1,0 +1,211 @@
+"""Thin Python owner of one ``use_handle`` (include/use_hip.h): uploads weights, plans the workspace for a
+(B, T') shape and forwards torch CUDA tensors' raw pointers and the current HIP stream.
+
+PyTorch is plumbing only here (device memory, streams); all arithmetic on the path runs in libuse_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import UseConfig, UseHipError, UseSamplerConfig, check
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_cuda_c64(name: str, t: torch.Tensor, shape=None) -> torch.Tensor:
+    if not t.is_cuda:
+        raise UseHipError(f"{name} must be a CUDA (ROCm) tensor: the sampling path has no CPU implementation")
+    if t.dtype != torch.complex64:
+        raise TypeError(f"{name} must be complex64, got {t.dtype}")
+    t = t.contiguous()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+class HipScoreEngine:
+    """One handle per (process, device).  Not re-entrant."""
+
+    def __init__(self, nf=128, ch_mult: Sequence[int] = (1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, n_freq=512,
+                 precision="bf16", device: Optional[int] = None, theta=1.5, sigma_min=0.05, sigma_max=0.5):
+        if precision not in _lib.PREC:
+            raise ValueError(f"precision must be one of {list(_lib.PREC)}, got {precision!r}")
+        self.L = _lib.lib()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        cfg = UseConfig()
+        cfg.nf, cfg.n_levels, cfg.num_res_blocks, cfg.n_freq = nf, len(ch_mult), num_res_blocks, n_freq
+        for i, m in enumerate(ch_mult):
+            cfg.ch_mult[i] = int(m)
+        cfg.precision = _lib.PREC[precision]
+        cfg.theta, cfg.sigma_min, cfg.sigma_max = theta, sigma_min, sigma_max
+        self.cfg, self.precision, self.n_freq = cfg, precision, n_freq
+        h = C.c_void_p()
+        check(self.L.use_create(C.byref(cfg), self.device, C.byref(h)), "use_create")
+        self.h = h
+        self.plan_shape = None
+        self.sampler_key = None
+        self.weights_ready = False
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.use_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ------------------------------------------------------------------------------------
+    def expected_weights(self) -> Dict[str, tuple]:
+        out = {}
+        n = check(self.L.use_num_expected_weights(self.h))
+        for i in range(n):
+            name, shape, nd = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+            check(self.L.use_expected_weight(self.h, i, C.byref(name), shape, C.byref(nd)))
+            out[name.value.decode()] = tuple(shape[: nd.value])
+        return out
+
+    def load_state_dict(self, sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str = ""):
+        """Upload weights given under the reference's state-dict keys (optionally behind ``prefix``)."""
+        for name in self.expected_weights():
+            key = prefix + name
+            if key not in sd:
+                raise KeyError(f"state dict is missing '{key}'")
+            v = sd[key]
+            a = v.detach().cpu().float().contiguous().numpy() if isinstance(v, torch.Tensor) else np.ascontiguousarray(v, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            check(self.L.use_set_weight(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim), f"use_set_weight({name})")
+        check(self.L.use_commit_weights(self.h), "use_commit_weights")
+        self.weights_ready = True
+        self.sampler_key = None
+
+    def weight_blob(self) -> torch.Tensor:
+        """uint8 CUDA view of the packed device blob (for a one-time RCCL broadcast from rank 0)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        check(self.L.use_weight_blob(self.h, C.byref(p), C.byref(n)))
+        if not p.value:
+            raise UseHipError("weight blob not allocated (call load_state_dict or alloc_weight_blob first)")
+
+        class _Iface:  # __cuda_array_interface__ shim: lets torch wrap library-owned device memory
+            pass
+        o = _Iface()
+        o.__cuda_array_interface__ = {"shape": (n.value,), "typestr": "|u1", "data": (p.value, False), "version": 2}
+        return torch.as_tensor(o, device=f"cuda:{self.device}")
+
+    def alloc_weight_blob(self):
+        check(self.L.use_alloc_weight_blob(self.h), "use_alloc_weight_blob")
+        self.weights_ready = True
+        self.sampler_key = None
+
+    # ---- planning -----------------------------------------------------------------------------------
+    def plan(self, B: int, Tpad: int):
+        if self.plan_shape != (B, Tpad):
+            check(self.L.use_plan(self.h, B, Tpad), "use_plan")
+            self.plan_shape = (B, Tpad)
+            self.sampler_key = None
+
+    def workspace_bytes(self) -> int:
+        n = C.c_size_t()
+        check(self.L.use_workspace_bytes(self.h, C.byref(n)))
+        return n.value
+
+    def flops_per_score(self) -> float:
+        return float(self.L.use_flops_per_score(self.h))
+
+    # ---- execution ----------------------------------------------------------------------------------
+    def score(self, x: torch.Tensor, y: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """-score_net(cat[x, y], t): x, y complex64 [B,1,F,T'] on this device, t float32 [B]."""
+        x = _require_cuda_c64("x", x)
+        y = _require_cuda_c64("y", y, x.shape)
+        B, _, Fq, T = x.shape
+        if Fq != self.n_freq:
+            raise ValueError(f"expected {self.n_freq} frequency bins, got {Fq}")
+        self.plan(B, T)
+        t = t.to(device=x.device, dtype=torch.float32).contiguous()
+        if t.numel() != B:
+            raise ValueError(f"t must have {B} elements")
+        out = torch.empty_like(x)
+        check(self.L.use_score(self.h, x.data_ptr(), y.data_ptr(), t.data_ptr(), out.data_ptr(), _stream_ptr(x.device)), "use_score")
+        return out
+
+    def set_sampler(self, N, predictor="reverse_diffusion", corrector="none", corrector_steps=1, snr=0.5, t_eps=3e-2,
+                    use_graph=True):
+        key = (self.plan_shape, N, predictor, corrector, corrector_steps, float(snr), float(t_eps), bool(use_graph))
+        if key == self.sampler_key:
+            return
+        sc = UseSamplerConfig(int(N), _lib.PREDICTORS[predictor], _lib.CORRECTORS[corrector], int(corrector_steps),
+                              float(snr), float(t_eps), int(bool(use_graph)))
+        check(self.L.use_set_sampler(self.h, C.byref(sc)), "use_set_sampler")
+        self.sampler_key = key
+
+    def num_noise_draws(self) -> int:
+        return check(self.L.use_num_noise_draws(self.h))
+
+    def timesteps(self) -> np.ndarray:
+        n = check(self.L.use_get_timesteps(self.h, (C.c_float * 1)(), 0))
+        buf = (C.c_float * n)()
+        check(self.L.use_get_timesteps(self.h, buf, n))
+        return np.array(buf[:], dtype=np.float32)
+
+    def sample(self, y: torch.Tensor, noise: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
+        """Run the configured PC sampler on y (complex64 [B,1,F,T']); returns x_mean of the last step."""
+        y = _require_cuda_c64("y", y)
+        if (y.shape[0], y.shape[3]) != self.plan_shape:
+            raise UseHipError(f"sampler planned for {self.plan_shape}, got B={y.shape[0]} T'={y.shape[3]}")
+        nptr = None
+        if noise is not None:
+            noise = _require_cuda_c64("noise", noise, (self.num_noise_draws(),) + tuple(y.shape))
+            nptr = noise.data_ptr()
+        out = torch.empty_like(y)
+        check(self.L.use_sample(self.h, y.data_ptr(), nptr, int(seed) & (2**64 - 1), out.data_ptr(), _stream_ptr(y.device)), "use_sample")
+        return out
+
+    def debug_tensor(self, name: str) -> torch.Tensor:
+        """Copy of a named intermediate of the last score evaluation as float32 [B,H,W,C]."""
+        p, dims, dt = C.c_void_p(), (C.c_int * 4)(), C.c_int()
+        check(self.L.use_debug_tensor(self.h, name.encode(), C.byref(p), dims, C.byref(dt)))
+        n = int(np.prod(dims[:]))
+
+        class _Iface:
+            pass
+        o = _Iface()
+        o.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4" if dt.value == 0 else "<u2", "data": (p.value, False), "version": 2}
+        raw = torch.as_tensor(o, device=f"cuda:{self.device}").clone()
+        if dt.value == 1:
+            raw = raw.view(torch.bfloat16)
+        return raw.float().view(*dims[:])
+
+    # ---- stand-alone SDE element-wise updates (use_sde_*) ----------------------------------------------
+    def sde_prior(self, y, noise=None, seed=0):
+        y = _require_cuda_c64("y", y)
+        x = torch.empty_like(y)
+        check(self.L.use_sde_prior(self.h, y.data_ptr(), None if noise is None else _require_cuda_c64("noise", noise, y.shape).data_ptr(),
+                                   int(seed), x.data_ptr(), y.numel(), _stream_ptr(y.device)), "use_sde_prior")
+        return x
+
+    def sde_predictor(self, predictor, t: float, N: int, x, y, score, noise=None, seed=0):
+        x = _require_cuda_c64("x", x)
+        y = _require_cuda_c64("y", y, x.shape); score = _require_cuda_c64("score", score, x.shape)
+        xo, xm = torch.empty_like(x), torch.empty_like(x)
+        check(self.L.use_sde_predictor(self.h, _lib.PREDICTORS[predictor], float(t), int(N), x.data_ptr(), y.data_ptr(), score.data_ptr(),
+                                       None if noise is None else _require_cuda_c64("noise", noise, x.shape).data_ptr(), int(seed),
+                                       xo.data_ptr(), xm.data_ptr(), x.numel(), _stream_ptr(x.device)), "use_sde_predictor")
+        return xo, xm
+
+    def sde_corrector(self, corrector, t: float, snr: float, x, score, noise=None, seed=0):
+        x = _require_cuda_c64("x", x)
+        score = _require_cuda_c64("score", score, x.shape)
+        xo, xm = torch.empty_like(x), torch.empty_like(x)
+        check(self.L.use_sde_corrector(self.h, _lib.CORRECTORS[corrector], float(t), float(snr), x.shape[0], x.data_ptr(), score.data_ptr(),
+                                       None if noise is None else _require_cuda_c64("noise", noise, x.shape).data_ptr(), int(seed),
+                                       xo.data_ptr(), xm.data_ptr(), x.numel(), _stream_ptr(x.device)), "use_sde_corrector")
+        return xo, xm
