@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Benchmark of the SGMSE reverse-SDE sampling path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over one batch: the 30-step predictor-corrector sampler
+(reverse_diffusion + Langevin x1, snr 0.5 => 60 score-network evaluations) on B=8 synthetic 4 s / 24 kHz utterances
+per GPU (BASELINE configs[1]; T=601 frames, padded T'=640, F=512), bf16 storage / fp32 accumulation, whole loop
+replayed as one hipGraph, device Philox noise.  Inputs (compressed STFT spectrograms) are resident in HBM before the
+timed region; STFT/iSTFT are outside it.  Multi-GPU: utterances are sharded over ranks (weak scaling,
+no data-path collective; one weight-blob broadcast at start-up).
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around every launch of the dominant
+kernel (the activation-dtype implicit-GEMM conv) during one eager score evaluation on the same stream;
+`cpu_baseline` times the CPU oracle (a port of the reference's path, validated against the reference's golden
+vectors) on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOP_PER_FRAME_NFE = 4.1657e9        # 2*MAC per padded frame per score evaluation (F=512)
+PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_FP32_TFLOPS = 157.3
+
+
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(sd_np):
+    """CPU oracle on a bounded sample: 1 utterance of 64 frames, one score evaluation per thread-count candidate
+    (the best is kept: torch's CPU conv does not scale to hundreds of threads on this shape), then N=1 PC step with
+    Langevin x1 (2 NFE) at the best thread count."""
+    from oracle import ncsnpp_oracle as no
+    from oracle import sde_oracle as so
+    from universal_speech_enhancement_amd.testing import noise as tn
+    avail = usable_cores()
+    sd = no.to_torch(sd_np)
+    L = 63 * 160
+    wav = torch.from_numpy(tn.synth_noisy_speech(1, L, seed=4242))
+    x = torch.from_numpy(tn.complex_normal(1, "cpu_x", (1, 2, 512, 64)))
+    best, best_dt = None, 1e30
+    with torch.no_grad():
+        for th in sorted({min(avail, c) for c in (8, 32, avail)}):
+            torch.set_num_threads(th)
+            t0 = time.time()
+            no.ncsnpp_forward(sd, x, torch.tensor([0.5]))
+            d = time.time() - t0
+            if d < best_dt:
+                best, best_dt = th, d
+            if d > 20.0:
+                break
+        torch.set_num_threads(best)
+        draws = [torch.from_numpy(d) for d in tn.sampler_noise(1, 3, (1, 1, 512, 64))]
+        t0 = time.time()
+        _, _, Y, nfe = so.score_model_sample(lambda xx, t: no.ncsnpp_forward(sd, xx, t), wav, N=1, corrector="langevin",
+                                             corrector_steps=1, snr=0.5, noise=so.NoiseSource(replay=draws))
+        dt = time.time() - t0
+    frames = 1 + L // 160
+    frame_nfe_per_s = frames * nfe / dt
+    return {"value": round(frame_nfe_per_s / 60.0, 4), "unit": "spectrogram-frames/s", "cores": best, "kind": "port",
+            "sample": f"CPU oracle (torch fp32, {best} of {avail} usable cores): 1 utterance x {frames} frames, N=1 PC step = "
+                      f"{nfe} NFE in {dt:.1f} s ({frame_nfe_per_s:.1f} frame*NFE/s), scaled linearly to 60 NFE"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--N", type=int, default=30, help="reverse steps")
+    ap.add_argument("--corrector", default="langevin")
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from universal_speech_enhancement_amd import distributed as D
+    from universal_speech_enhancement_amd.hip_engine import HipScoreEngine
+    from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel
+    from universal_speech_enhancement_amd.testing import noise as tn
+    from universal_speech_enhancement_amd.testing import weights as tw
+
+    rank, world, local = D.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # ---- weights: rank 0 builds + packs, one broadcast of the packed blob (RCCL over xGMI) ----
+    sd_np = tw.make_state_dict(1234, **tw.LARGE) if rank == 0 else None
+    eng = HipScoreEngine(precision=a.precision, device=local)
+    D.broadcast_weights(eng, sd_np, src=0)
+
+    # ---- synthetic 24 kHz noisy speech -> compressed, padded STFT spectrograms resident in HBM ----
+    L = int(a.seconds * 24000)
+    glue = ScoreModel(backbone="none", condition="noisy", n_fft=1022, hop_length=160, num_frames=512, sde_input="noisy")
+    wav = torch.from_numpy(tn.synth_noisy_speech(a.batch, L, seed=1234 + rank * a.batch)).to(dev)
+    Y = glue._spectrogram(wav).contiguous()
+    B, _, Fq, Tp = Y.shape
+    T = 1 + L // 160
+    ncorr = 0 if a.corrector == "none" else 1
+    nfe = a.N * (1 + ncorr)
+    eng.plan(B, Tp)
+    eng.set_sampler(a.N, "reverse_diffusion", a.corrector, 1, 0.5, 3e-2, use_graph=not a.no_graph)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for w in range(a.warmup):
+        eng.sample(Y, seed=4321 + w)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        out = eng.sample(Y, seed=4321 + a.warmup + k)
+    barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+    assert torch.isfinite(torch.view_as_real(out)).all(), "non-finite sampler output"
+
+    frames = world * B * T * a.steps
+    value = frames / dt
+    ms_per_step = dt / a.steps * 1e3
+    padded_frame_nfe_per_s = world * B * Tp * nfe * a.steps / dt
+    tflops_path = padded_frame_nfe_per_s * FLOP_PER_FRAME_NFE / 1e12 / world     # per GPU
+
+    # ---- roofline of the dominant kernel, HIP events per launch on the current stream ----
+    x = out
+    tvec = torch.full((B,), 0.5, device=dev)
+    eng.profile_score(x, Y, tvec)                                   # warm
+    conv_ms, conv_flops, conv_launches, total_ms = eng.profile_score(x, Y, tvec)
+    peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_FP32_TFLOPS
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "kernel": "use::conv_kernel<%s> (implicit-GEMM 3x3/1x1, BN=128)" % ("bf16,bf16,CK=64" if a.precision == "bf16" else "f32,f32,CK=32"),
+                "launches_per_score": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
+                "algorithmic_gflop_per_launch": round(conv_flops / max(conv_launches, 1) / 1e9, 2),
+                "kernel_time_share_of_score": round(conv_ms / total_ms, 3),
+                "whole_path_tflops_per_gpu": round(tflops_path, 1), "whole_path_frac": round(tflops_path / peak, 4)}
+
+    if rank == 0:
+        res = {
+            "metric": "spectrogram-frames/sec through 30-step PC sampler, 24 kHz" if (a.N, ncorr) == (30, 1)
+                      else f"spectrogram-frames/sec through {a.N}-step sampler ({nfe} NFE), 24 kHz",
+            "value": round(value, 2), "unit": "spectrogram-frames/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": f"configs[1]: NCSN++ Large score net, batch={B}x{a.seconds:g} s utterances per GPU, "
+                                   f"{a.N}-step PC sampler (reverse_diffusion + {a.corrector} x1, snr 0.5, {nfe} NFE), "
+                                   f"{a.precision}, hipGraph={'off' if a.no_graph else 'on'}",
+                       "global_batch": world * B, "frames_per_utt": T, "padded_frames_per_utt": Tp, "n_freq": Fq,
+                       "N": a.N, "nfe": nfe, "parallelism": f"utterance-sharded x{world}"},
+            "padded_frame_nfe_per_s": round(padded_frame_nfe_per_s, 1),
+            "roofline": roofline,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd_np)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

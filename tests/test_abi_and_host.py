@@ -1,0 +1,149 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/use_hip.h declares, the C++
+architecture walk agrees with the reference's state-dict layout, error paths report instead of crashing, and the
+host-side mirror of the reference interface behaves like the reference's (registries, pad_spec, ScoreModel keys)."""
+import ctypes as C
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from universal_speech_enhancement_amd import _lib
+from universal_speech_enhancement_amd.sgmse.backbones import BackboneRegistry
+from universal_speech_enhancement_amd.sgmse.backbones.arch import ncsnpp_param_shapes
+from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel
+from universal_speech_enhancement_amd.sgmse.sampling import CorrectorRegistry, PredictorRegistry
+from universal_speech_enhancement_amd.sgmse.sdes import OUVESDE, SDERegistry
+from universal_speech_enhancement_amd.sgmse.util.other import pad_spec
+from universal_speech_enhancement_amd.sgmse.util.registry import Registry
+from universal_speech_enhancement_amd.testing import weights as tw
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(nf=128, mult=(1, 1, 2, 2, 2, 2, 2), nrb=2, n_freq=512, prec=1):
+    cfg = _lib.UseConfig()
+    cfg.nf, cfg.n_levels, cfg.num_res_blocks, cfg.n_freq, cfg.precision = nf, len(mult), nrb, n_freq, prec
+    for i, m in enumerate(mult):
+        cfg.ch_mult[i] = m
+    cfg.theta, cfg.sigma_min, cfg.sigma_max = 1.5, 0.05, 0.5
+    return cfg
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "use_hip.h")).read()
+    declared = set(re.findall(r"\b(use_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no prototypes parsed"
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in use_hip.h but not exported"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert b"gfx950" in _lib.lib().use_version()
+
+
+def test_architecture_walk_matches_reference_state_dict_layout():
+    L = _lib.lib()
+    for arch in (tw.LARGE, dict(nf=128, ch_mult=(1, 2, 2, 2), num_res_blocks=1, input_channels=4),
+                 dict(nf=64, ch_mult=(1, 2), num_res_blocks=3, input_channels=4)):
+        h = C.c_void_p()
+        assert L.use_create(C.byref(_cfg(arch["nf"], arch["ch_mult"], arch["num_res_blocks"])), 0, C.byref(h)) == 0
+        want = ncsnpp_param_shapes(**arch)
+        got = {}
+        for i in range(L.use_num_expected_weights(h)):
+            name, shape, nd = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+            assert L.use_expected_weight(h, i, C.byref(name), shape, C.byref(nd)) == 0
+            got[name.value.decode()] = tuple(shape[: nd.value])
+        assert got == dict(want)
+        assert L.use_destroy(h) == 0
+
+
+def test_error_paths_report_and_do_not_crash():
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.use_create(C.byref(_cfg(nf=100)), 0, C.byref(h)) == -1 and b"nf" in L.use_last_error()
+    assert L.use_create(C.byref(_cfg(prec=7)), 0, C.byref(h)) == -1
+    assert L.use_create(C.byref(_cfg()), 0, C.byref(h)) == 0
+    a = np.zeros((3, 3), np.float32)
+    shp = (C.c_int64 * 2)(3, 3)
+    assert L.use_set_weight(h, b"not.a.weight", a.ctypes.data_as(C.c_void_p), shp, 2) == -1
+    assert b"unexpected weight name" in L.use_last_error()
+    assert L.use_set_weight(h, b"output_layer.bias", a.ctypes.data_as(C.c_void_p), shp, 2) == -1
+    assert L.use_score(h, None, None, None, None, None) == -3            # weights not committed
+    assert L.use_num_noise_draws(h) == -3
+    with pytest.raises(_lib.UseHipError):
+        _lib.check(L.use_plan(h, 0, 64), "use_plan")
+    assert L.use_destroy(h) == 0
+
+
+def test_timesteps_equal_torch_linspace():
+    L = _lib.lib()
+    for N in (1, 2, 5, 7, 30, 50, 200):
+        buf = (C.c_float * N)()
+        assert L.use_timesteps(N, 0.03, buf) == 0
+        np.testing.assert_array_equal(np.array(buf[:], np.float32), torch.linspace(1, 0.03, N).numpy())
+
+
+def test_registry_semantics():
+    r = Registry("Thing")
+
+    @r.register("a")
+    class A:  # noqa: D401
+        pass
+    assert r.get_by_name("a") is A and r.get_all_names() == ["a"]
+    with pytest.raises(ValueError, match="Thing with name 'b' unknown"):
+        r.get_by_name("b")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        r.register("a")(A)
+        assert any("doubly registered" in str(x.message) for x in w)
+    assert {"reverse_diffusion", "euler_maruyama", "none"} <= set(PredictorRegistry.get_all_names())
+    assert {"langevin", "ald", "none"} <= set(CorrectorRegistry.get_all_names())
+    assert "ouve" in SDERegistry.get_all_names()
+    assert {"ncsnpp", "ncsnpplarge"} <= set(BackboneRegistry.get_all_names())
+
+
+def test_pad_spec_and_stft_glue():
+    Y = torch.zeros(2, 1, 512, 61, dtype=torch.complex64)
+    assert pad_spec(Y).shape[-1] == 64 and pad_spec(pad_spec(Y)).shape[-1] == 64
+    assert pad_spec(torch.zeros(1, 1, 4, 128)).shape[-1] == 128
+    m = ScoreModel(backbone="none", condition="noisy", n_fft=1022, hop_length=160, num_frames=512, sde_input="noisy")
+    wav = torch.randn(2, 9600)
+    S = m.stft(wav)
+    assert S.shape == (2, 512, 61)
+    back = m.spec_back(m.spec_fwd(S))
+    assert torch.allclose(back, S, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(m.istft(S, 9600), wav, atol=1e-4)
+
+
+def test_score_model_state_dict_layout_and_no_cpu_fallback():
+    m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition="noisy", n_fft=1022, hop_length=160,
+                   num_frames=512, window="hann", sde_input="noisy")
+    assert isinstance(m.sde, OUVESDE) and m.predictor == "reverse_diffusion" and m.corrector == "none"
+    sd = m.state_dict()
+    want = ncsnpp_param_shapes(**tw.LARGE)
+    assert [k[len("score_net."):] for k in sd] == list(want)
+    assert sum(v.numel() for v in sd.values()) == 64799782
+    # CPU tensors must be refused loudly (there is no CPU implementation of the product path)
+    with pytest.raises(_lib.UseHipError):
+        z = torch.zeros(1, 1, 512, 64, dtype=torch.complex64)
+        m(z, torch.ones(1), [z], z)
+    with pytest.raises(NotImplementedError):
+        ScoreModel(backbone="ncsnpplarge", condition="both")
+    with pytest.raises(ValueError):
+        ScoreModel(backbone="no_such_backbone", condition="noisy")
+
+
+def test_ouve_sde_host_math_matches_oracle():
+    from oracle import sde_oracle as so
+    sde = OUVESDE()
+    t = torch.tensor([1.0, 0.5, 0.03])
+    np.testing.assert_allclose(sde._std(t).numpy(), so.ouve_std(t).numpy(), rtol=1e-6)
+    x, y = torch.randn(3, 1, 4, 4, dtype=torch.complex64), torch.randn(3, 1, 4, 4, dtype=torch.complex64)
+    d1, g1 = sde.sde(x, t, y)
+    d2, g2 = so.ouve_sde(x, t, y)
+    assert torch.equal(d1, d2) and torch.equal(g1, g2)
+    sde.N = 30
+    f, G = sde.discretize(x, t, y)
+    assert torch.allclose(G, g1 * (1 / 30) ** 0.5)

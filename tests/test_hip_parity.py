@@ -1,0 +1,250 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference's golden vectors and the CPU oracle.
+
+Tolerances (relative to the reference tensor's max magnitude unless stated):
+  fp32 storage  : one score evaluation  <= 5e-4   (measured 3e-6 .. 5e-5)
+                  whole sampler, waveform <= 2e-3
+  bf16 storage  : one score evaluation  <= 6e-2   (measured ~2e-2; CPU bf16-autocast of the reference: 2.5e-2)
+                  whole sampler, waveform <= 1.5e-1 (stochastic-sampler error compounding, N<=5)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ncsnpp_oracle as no
+from oracle import sde_oracle as so
+from universal_speech_enhancement_amd._lib import UseHipError
+from universal_speech_enhancement_amd.testing import noise as tnoise
+from universal_speech_enhancement_amd.testing import weights as tw
+
+pytestmark = pytest.mark.gpu
+
+
+def _relmax(a, b):
+    a, b = torch.as_tensor(a).cpu(), torch.as_tensor(b).cpu()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+@pytest.fixture(scope="module")
+def sd_np():
+    return tw.make_state_dict(1234, **tw.LARGE)
+
+
+@pytest.fixture(scope="module")
+def engines(sd_np):
+    from universal_speech_enhancement_amd.hip_engine import HipScoreEngine
+    out = {}
+    for prec in ("fp32", "bf16"):
+        e = HipScoreEngine(precision=prec)
+        e.load_state_dict(sd_np)
+        out[prec] = e
+    yield out
+    for e in out.values():
+        e.close()
+
+
+def _score_model(sd_np, precision, corrector="langevin", use_graph=True):
+    from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel
+    m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition="noisy", n_fft=1022, hop_length=160,
+                   num_frames=512, window="hann", sde_input="noisy", predictor="reverse_diffusion", corrector=corrector,
+                   precision=precision, use_graph=use_graph)
+    m.score_net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    return m
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", 6e-2)])
+def test_score_matches_reference_golden(golden_dir, engines, prec, tol):
+    g = dict(np.load(os.path.join(golden_dir, "forward_large.npz")))
+    x = torch.from_numpy(g["x"]).cuda()
+    for tag in ("a", "b"):
+        out = engines[prec].score(x[:, 0:1].contiguous(), x[:, 1:2].contiguous(), torch.from_numpy(g["t_" + tag]).cuda())
+        err = _relmax(out, -torch.from_numpy(g["out_" + tag]))        # library returns score = -net
+        assert err < tol, (prec, tag, err)
+
+
+def test_intermediate_taps_match_oracle_fp32(golden_dir, engines, sd_np):
+    g = dict(np.load(os.path.join(golden_dir, "forward_large.npz")))
+    x = torch.from_numpy(g["x"])
+    t = torch.from_numpy(g["t_b"])
+    taps = {}
+    with torch.no_grad():
+        no.ncsnpp_forward(no.to_torch(sd_np), x, t, taps=taps)
+    xc = x.cuda()
+    engines["fp32"].score(xc[:, 0:1].contiguous(), xc[:, 1:2].contiguous(), t.cuda())
+    for name in ("h_in", "pre_attn", "post_attn", "pyramid"):
+        got = engines["fp32"].debug_tensor(name).permute(0, 3, 1, 2)
+        assert _relmax(got, taps[name]) < 5e-4, name
+
+
+def test_backbone_interface_returns_network_output(golden_dir, sd_np):
+    from universal_speech_enhancement_amd.sgmse.backbones import BackboneRegistry
+    g = dict(np.load(os.path.join(golden_dir, "forward_large.npz")))
+    net = BackboneRegistry.get_by_name("ncsnpplarge")(input_channels=4, precision="fp32")
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    out = net(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t_a"]).cuda())
+    assert out.shape == (2, 1, 512, 64) and out.dtype == torch.complex64
+    assert _relmax(out, g["out_a"]) < 5e-4
+
+
+@pytest.mark.parametrize("corr", ["none", "langevin", "ald"])
+def test_sde_update_kernels_match_reference_sampler(golden_dir, corr):
+    """Seam path: reference-style loop over the registries with an analytic score_fn; every update runs in
+    use_sde_* kernels; compared with the reference's own sampler output (golden)."""
+    from universal_speech_enhancement_amd.sgmse import sampling
+    from universal_speech_enhancement_amd.sgmse.sdes import OUVESDE
+    g = dict(np.load(os.path.join(golden_dir, f"sampler_rd_{corr}.npz")))
+    Y, A = torch.from_numpy(g["Y"]).cuda(), torch.from_numpy(g["A"]).cuda()
+    draws = torch.from_numpy(tnoise.sampler_noise(int(g["noise_seed"]), int(g["n_draws"]), tuple(Y.shape))).cuda()
+
+    def score_fn(x, t, score_conditioning=None, sde_input=None):
+        return -(x - 0.8 * sde_input) / (0.1 + t[:, None, None, None] ** 2) + 0.05 * A * torch.tanh(x.abs())
+
+    sde = OUVESDE(); sde.N = int(g["N"])
+    x, nfe = sampling.get_pc_sampler("reverse_diffusion", corr, sde=sde, score_fn=score_fn, y=Y, eps=float(g["eps"]),
+                                     snr=float(g["snr"]), corrector_steps=int(g["corrector_steps"]), conditioning=[Y],
+                                     noise=draws)()
+    assert nfe == int(g["nfe"])
+    np.testing.assert_allclose(x.cpu().numpy(), g["x"], rtol=2e-4, atol=2e-5)
+
+
+def test_euler_maruyama_equals_reverse_diffusion_update():
+    """For the OUVE SDE the two predictors are the same map up to rounding (f dt, g sqrt(dt))."""
+    from universal_speech_enhancement_amd.sgmse.sampling import _sde_engine
+    from universal_speech_enhancement_amd.sgmse.sdes import OUVESDE
+    eng = _sde_engine(OUVESDE(), "cuda")
+    sh = (2, 1, 32, 16)
+    x, y, s, z = (torch.from_numpy(tnoise.complex_normal(5, k, sh)).cuda() for k in "xysz")
+    a, am = eng.sde_predictor("reverse_diffusion", 0.4, 30, x, y, s, noise=z)
+    b, bm = eng.sde_predictor("euler_maruyama", 0.4, 30, x, y, s, noise=z)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6) and torch.allclose(am, bm, rtol=1e-5, atol=1e-6)
+    ref, ref_mean = so.predictor_euler_maruyama(x.cpu(), torch.full((2,), 0.4), y.cpu(), lambda xx, tt: s.cpu(), 30,
+                                                so.NoiseSource(replay=[z.cpu()]))
+    assert torch.allclose(b.cpu(), ref, rtol=1e-5, atol=1e-6) and torch.allclose(bm.cpu(), ref_mean, rtol=1e-5, atol=1e-6)
+
+
+def test_device_philox_noise_statistics():
+    from universal_speech_enhancement_amd.sgmse.sampling import _sde_engine
+    from universal_speech_enhancement_amd.sgmse.sdes import OUVESDE
+    eng = _sde_engine(OUVESDE(), "cuda")
+    y = torch.zeros(4, 1, 512, 64, dtype=torch.complex64, device="cuda")
+    std1 = float(so.ouve_std(torch.ones(1)))
+    z1 = eng.sde_prior(y, seed=7) / std1
+    z2 = eng.sde_prior(y, seed=7) / std1
+    z3 = eng.sde_prior(y, seed=8) / std1
+    assert torch.equal(z1, z2) and not torch.equal(z1, z3)
+    r = torch.view_as_real(z1)
+    assert abs(float(r.mean())) < 5e-3 and abs(float(r.var()) - 0.5) < 5e-3
+    assert abs(float((r[..., 0] * r[..., 1]).mean())) < 5e-3
+    assert abs(float((r ** 4).mean()) / float(r.var()) ** 2 - 3.0) < 0.1       # Gaussian kurtosis
+
+
+def _e2e(golden_dir, name, sd_np, precision, use_graph):
+    g = dict(np.load(os.path.join(golden_dir, name)))
+    wav = torch.from_numpy(g["wav"]).cuda()
+    Tp = (1 + wav.shape[1] // 160 + 63) // 64 * 64
+    draws = torch.from_numpy(tnoise.sampler_noise(int(g["noise_seed"]), int(g["n_draws"]), (wav.shape[0], 1, 512, Tp))).cuda()
+    m = _score_model(sd_np, precision, use_graph=use_graph)
+    out = m.sample({"perturbed": wav}, N=int(g["N"]), corrector_steps=int(g["corrector_steps"]), snr=float(g["snr"]),
+                   noise=draws)["enhanced"]
+    return out.cpu(), torch.from_numpy(g["enhanced"])
+
+
+def test_fused_sampler_fp32_matches_reference_end_to_end(golden_dir, sd_np):
+    out_graph, ref = _e2e(golden_dir, "sample_e2e.npz", sd_np, "fp32", True)
+    assert out_graph.shape == ref.shape
+    assert _relmax(out_graph, ref) < 2e-3
+    out_eager, _ = _e2e(golden_dir, "sample_e2e.npz", sd_np, "fp32", False)
+    assert torch.equal(out_graph, out_eager), "hipGraph replay must be bit-identical to eager launches"
+
+
+def test_fused_sampler_bf16_end_to_end_tolerance(golden_dir, sd_np):
+    out, ref = _e2e(golden_dir, "sample_e2e.npz", sd_np, "bf16", True)
+    assert _relmax(out, ref) < 1.5e-1
+
+
+def test_cfg1_plumbing_config_matches_reference(golden_dir, sd_np):
+    """BASELINE configs[0]: one 2 s utterance, 5 PC steps (reverse_diffusion + langevin)."""
+    out, ref = _e2e(golden_dir, "sample_cfg1.npz", sd_np, "fp32", True)
+    assert _relmax(out, ref) < 2e-3
+
+
+def test_seam_path_equals_fused_path_fp32(golden_dir, sd_np):
+    """Python-driven loop over the registries (score_fn = ScoreModel.forward -> use_score) vs use_sample."""
+    from universal_speech_enhancement_amd.sgmse import sampling
+    g = dict(np.load(os.path.join(golden_dir, "sample_e2e.npz")))
+    m = _score_model(sd_np, "fp32")
+    Y = m._spectrogram(torch.from_numpy(g["wav"]).cuda())
+    draws = torch.from_numpy(tnoise.sampler_noise(99, 1 + 2 * 2, tuple(Y.shape))).cuda()
+    fused, n1 = m.get_pc_sampler("reverse_diffusion", "ald", Y, N=2, corrector_steps=1, snr=0.5, conditioning=[Y], noise=draws)()
+    sde = m.sde.copy(); sde.N = 2
+    seam, n2 = sampling.get_pc_sampler("reverse_diffusion", "ald", sde=sde, score_fn=lambda x, t, score_conditioning=None, sde_input=None: m(x, t, score_conditioning, sde_input),
+                                       y=Y, eps=m.t_eps, snr=0.5, corrector_steps=1, conditioning=[Y], noise=draws)()
+    assert n1 == n2 == 4
+    assert _relmax(seam, fused) < 1e-5
+
+
+def test_full_size_properties_cfg2_bf16(sd_np):
+    """BASELINE configs[1] shape (8 x 4 s) with N=2: size-independent properties -- determinism under a fixed seed,
+    seed sensitivity, finiteness, and batch-item independence for a sampler without batch coupling (ALD)."""
+    m = _score_model(sd_np, "bf16", corrector="ald")
+    wav = torch.from_numpy(tnoise.synth_noisy_speech(8, 96000)).cuda()
+    a = m.sample({"perturbed": wav}, N=2, seed=11)["enhanced"]
+    b = m.sample({"perturbed": wav}, N=2, seed=11)["enhanced"]
+    c = m.sample({"perturbed": wav}, N=2, seed=12)["enhanced"]
+    assert a.shape == (8, 96000) and torch.isfinite(a).all()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    Y = m._spectrogram(wav)
+    assert Y.shape == (8, 1, 512, 640)
+    draws = torch.from_numpy(tnoise.sampler_noise(3, 5, (8, 1, 512, 640))).cuda()
+    full, _ = m.get_pc_sampler("reverse_diffusion", "ald", Y, N=2, conditioning=[Y], noise=draws)()
+    Y2 = Y[2:4].contiguous()
+    part, _ = m.get_pc_sampler("reverse_diffusion", "ald", Y2, N=2, conditioning=[Y2], noise=draws[:, 2:4].contiguous())()
+    assert torch.equal(full[2:4], part), "items must not interact when the corrector has no batch coupling"
+
+
+def test_langevin_step_couples_the_local_batch_like_the_reference(sd_np):
+    """LangevinCorrector averages norms over the batch (correctors.py:55-57): check against the oracle formula."""
+    from universal_speech_enhancement_amd.sgmse.sampling import _sde_engine
+    from universal_speech_enhancement_amd.sgmse.sdes import OUVESDE
+    eng = _sde_engine(OUVESDE(), "cuda")
+    sh = (3, 1, 64, 32)
+    x, g, z = (torch.from_numpy(tnoise.complex_normal(17, k, sh)) for k in "xgz")
+    g = g * torch.tensor([1.0, 5.0, 0.2]).view(3, 1, 1, 1)
+    got, got_mean = eng.sde_corrector("langevin", 0.5, 0.5, x.cuda(), g.cuda(), noise=z.cuda())
+    ref, ref_mean = so.corrector_langevin(x, torch.full((3,), 0.5), None, lambda xx, tt: g, 0.5, 1, so.NoiseSource(replay=[z]))
+    assert torch.allclose(got.cpu(), ref, rtol=1e-5, atol=1e-6) and torch.allclose(got_mean.cpu(), ref_mean, rtol=1e-5, atol=1e-6)
+
+
+def test_edge_cases_and_error_behaviour(sd_np, engines):
+    m = _score_model(sd_np, "bf16", corrector="none")
+    # ragged length: 0.25 s + 7 samples -> T = 38 frames -> padded to 64; B = 1; N = 1
+    wav = torch.from_numpy(tnoise.synth_noisy_speech(1, 6007)).cuda()
+    out = m.sample({"perturbed": wav}, N=1)["enhanced"]
+    assert out.shape == (1, 6007) and torch.isfinite(out).all()
+    with pytest.raises(UseHipError):
+        engines["bf16"].score(torch.zeros(1, 1, 512, 64, dtype=torch.complex64), torch.zeros(1, 1, 512, 64, dtype=torch.complex64), torch.ones(1))
+    with pytest.raises(TypeError):
+        engines["bf16"].score(torch.zeros(1, 1, 512, 64, device="cuda"), torch.zeros(1, 1, 512, 64, device="cuda"), torch.ones(1))
+    with pytest.raises(UseHipError, match="multiple of 64"):
+        z = torch.zeros(1, 1, 512, 60, dtype=torch.complex64, device="cuda")
+        engines["bf16"].score(z, z, torch.ones(1))
+    with pytest.raises(ValueError):
+        z = torch.zeros(1, 1, 256, 64, dtype=torch.complex64, device="cuda")
+        engines["bf16"].score(z, z, torch.ones(1))
+
+
+def test_predict_step_writes_trimmed_wavs(tmp_path, sd_np):
+    from scipy.io import wavfile
+    from universal_speech_enhancement_amd.SGMSE_module import SGMSEModule
+    mod = SGMSEModule(Score=_score_model(sd_np, "bf16", corrector="none"), sampler_kwargs=dict(N=1))
+    src, dst = str(tmp_path / "in"), str(tmp_path / "out")
+    wav = torch.from_numpy(tnoise.synth_noisy_speech(2, 8000)).cuda()
+    batch = {"perturbed": wav, "name": ["a", "b"], "sample_length": torch.tensor([8000, 5000], dtype=torch.int32),
+             "sampling_rate": [24000, 24000], "audio_path": [f"{src}/x/a.wav", f"{src}/b.wav"], "data_folder": src,
+             "target_folder": dst}
+    out = mod.predict_step(batch, 0)
+    assert out["enhanced"].shape == (2, 8000)
+    sr, a = wavfile.read(f"{dst}/x/a.wav"); _, b = wavfile.read(f"{dst}/b.wav")
+    assert sr == 24000 and a.shape == (8000,) and b.shape == (5000,) and a.dtype == np.float32
+    np.testing.assert_allclose(b, out["enhanced"][1, :5000].cpu().numpy(), atol=1e-6)

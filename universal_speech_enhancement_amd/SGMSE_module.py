@@ -1,0 +1,55 @@
+"""``SGMSEModule`` with the constructor and ``predict_step`` contract of the reference's
+``src/models/SGMSE_module.py:10-82`` -- without the Lightning dependency (absent on the target image): a plain
+``nn.Module`` whose ``predict_step(batch, batch_idx)`` runs ``Score.sample(batch)``, trims every item to
+``sample_length`` and writes it to ``audio_path.replace(data_folder, target_folder)``.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+
+def _write_wav(path: str, wav: np.ndarray, sr: int):
+    try:
+        import soundfile as sf  # the reference's writer (SGMSE_module.py:80)
+        sf.write(path, wav, sr)
+    except ImportError:
+        from scipy.io import wavfile
+        wavfile.write(path, int(sr), wav.astype(np.float32))
+
+
+class SGMSEModule(torch.nn.Module):
+    def __init__(self, Score: torch.nn.Module, optimizer=None, scheduler=None, compile: bool = False, sampler_kwargs=None):
+        super().__init__()
+        self.Score = Score
+        self.optimizer, self.scheduler, self.compile = optimizer, scheduler, compile
+        self.sampler_kwargs = dict(sampler_kwargs or {})     # optional N / corrector_steps / snr overrides
+
+    def load_lightning_checkpoint(self, path: str, map_location="cpu"):
+        """Loads ``ckpt['state_dict']`` with the reference's key layout (``Score.score_net.all_modules...``)."""
+        ckpt = torch.load(path, map_location=map_location, weights_only=False)
+        sd = ckpt.get("state_dict", ckpt)
+        missing, unexpected = self.load_state_dict(sd, strict=False)
+        if missing:
+            raise KeyError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[:3]}")
+        return unexpected
+
+    @torch.no_grad()
+    def predict_step(self, batch: dict, batch_idx: int = 0) -> dict:
+        batch = self.Score.sample(batch, **self.sampler_kwargs)
+        for i, enhanced in enumerate(batch["enhanced"]):
+            if "audio_path" not in batch:
+                continue
+            noisy_path = batch["audio_path"][i]
+            sample_length = int(batch["sample_length"][i])
+            sample_rate = batch["sampling_rate"][i]
+            enhanced_path = noisy_path.replace(batch["data_folder"], batch["target_folder"])
+            os.makedirs(os.path.dirname(enhanced_path) or ".", exist_ok=True)
+            wav = enhanced.detach().cpu().numpy().astype(np.float32)[:sample_length]
+            _write_wav(enhanced_path, wav, sample_rate)
+        return batch
+
+    def training_step(self, *a, **k):
+        raise NotImplementedError("training is outside the scope of the MI355X sampling library")

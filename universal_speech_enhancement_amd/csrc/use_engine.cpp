@@ -109,6 +109,8 @@ struct use_handle {
     // scratch for the stand-alone use_sde_* entry points (independent of weights / plan)
     char* sde_buf = nullptr; unsigned long long* sde_rng = nullptr; float* sde_step = nullptr; float* sde_partial = nullptr;
     static constexpr int SDE_MAX_B = 1024, SDE_BLOCKS = 128;
+    // per-launch HIP-event profiling of the dominant conv kernel (use_profile_score)
+    bool profile = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_flops;
     // introspection
     bool dry = false;
     std::map<std::string, Act> debug;
@@ -331,7 +333,17 @@ struct Fwd {
         p.pyr = pyr; p.w4 = cb ? W<float>(cb->w_off) : nullptr; p.b4 = cb ? W<float>(cb->b_off) : nullptr;
         p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
         p.B = h->B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
-        launch_conv(p, s);
+        const bool main_variant = a.dtype == h->act_dtype && out_dtype == h->act_dtype && w.cout > 32;
+        if (h->profile && main_variant) {
+            hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, s);
+            launch_conv(p, s);
+            (void)hipEventRecord(e1, s);
+            h->prof_events.push_back({e0, e1});
+            h->prof_flops.push_back(2.0 * h->B * a.H * a.W * (double)w.cout * w.cin * w.ntaps);
+        } else {
+            launch_conv(p, s);
+        }
         return o;
     }
 
@@ -455,13 +467,14 @@ static float ouve_diffusion(const use_config& c, float t) {
     const float sigma = c.sigma_min * std::pow(c.sigma_max / c.sigma_min, t);     // float32 like the reference
     return (float)((double)sigma * std::sqrt(2 * ouve_logsig(c)));
 }
-// torch.linspace(start, end, steps) float32 CPU semantics (symmetric fill from both ends)
+// torch.linspace(start, end, steps) float32 CPU semantics: symmetric fill from both ends, each element one fused
+// multiply-add (matches the ATen CPU kernel bit-for-bit on the build container for N in 1..200)
 static void linspace_f32(float start, float end, int steps, std::vector<float>& out) {
     out.resize(steps);
     if (steps == 1) { out[0] = start; return; }
     const float step = (end - start) / (float)(steps - 1);
     const int half = steps / 2;
-    for (int i = 0; i < steps; ++i) out[i] = i < half ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+    for (int i = 0; i < steps; ++i) out[i] = i < half ? std::fmaf(step, (float)i, start) : std::fmaf(-step, (float)(steps - 1 - i), end);
 }
 
 static void predictor_coeffs(const use_config& c, int predictor, float t, int N, float& cd, float& cs, float& cn) {
@@ -695,6 +708,41 @@ int use_score(use_handle* h, const void* x, const void* y, const float* t, void*
     run_temb(h, t, h->B, h->silu_temb, h->tembias, s);
     run_score(h, (const float2*)x, (const float2*)y, h->tembias, h->dense_rows, t, 1, (float2*)out, s);
     HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+
+int use_profile_score(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream,
+                      double* conv_ms, double* conv_flops, int* conv_launches, double* total_ms) {
+    int rc = check_ready(h); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t t0, t1; HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    h->profile = true; h->prof_events.clear(); h->prof_flops.clear();
+    HIPCHK(hipEventRecord(t0, s));
+    rc = use_score(h, x, y, t, out, stream);
+    h->profile = false;
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(t1, s));
+    HIPCHK(hipStreamSynchronize(s));
+    double ms = 0.0, fl = 0.0;
+    for (size_t i = 0; i < h->prof_events.size(); ++i) {
+        float e = 0.f; HIPCHK(hipEventElapsedTime(&e, h->prof_events[i].first, h->prof_events[i].second));
+        ms += e; fl += h->prof_flops[i];
+        (void)hipEventDestroy(h->prof_events[i].first); (void)hipEventDestroy(h->prof_events[i].second);
+    }
+    float tot = 0.f; HIPCHK(hipEventElapsedTime(&tot, t0, t1));
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    if (conv_ms) *conv_ms = ms;
+    if (conv_flops) *conv_flops = fl;
+    if (conv_launches) *conv_launches = (int)h->prof_events.size();
+    if (total_ms) *total_ms = tot;
+    h->prof_events.clear(); h->prof_flops.clear();
+    return USE_OK;
+}
+
+int use_timesteps(int N, float t_eps, float* out) {
+    if (N < 1 || !out) return fail(USE_E_INVALID, "bad arguments");
+    std::vector<float> ts; linspace_f32(1.0f, t_eps, N, ts);
+    memcpy(out, ts.data(), (size_t)N * 4);
     return USE_OK;
 }
 

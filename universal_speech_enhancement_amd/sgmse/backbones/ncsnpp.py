@@ -1,0 +1,128 @@
+"""HIP-backed NCSN++ score network behind the reference's backbone interface.
+
+``BackboneRegistry.get_by_name("ncsnpplarge")(input_channels=4)`` returns an ``nn.Module`` whose
+``state_dict()`` has exactly the reference's keys and shapes (reference ``sgmse/backbones/ncsnpp.py:116-316``:
+``all_modules.<i>....``, ``output_layer.*``), so Lightning checkpoints of the reference load unchanged, and whose
+``forward(x, time_cond)`` (reference :324-501: x complex [B,2,F,T'] = cat[x_t, Y], time_cond [B] ->
+complex [B,1,F,T']) runs in libuse_hip.so.  The module holds parameters only; there is no PyTorch forward.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .arch import ncsnpp_param_shapes
+from .shared import BackboneRegistry
+
+
+class _Holder(nn.Module):
+    """Parameter container; nesting reproduces the reference's dotted key names."""
+
+
+def _fan_avg_uniform(shape, scale, gen):
+    """``default_init(scale)`` = variance_scaling(scale, 'fan_avg', 'uniform') (reference layers.py:66-103)."""
+    scale = 1e-10 if scale == 0 else scale
+    rf = int(np.prod(shape[2:])) if len(shape) > 2 else 1
+    fan_in, fan_out = shape[1] * rf, shape[0] * rf
+    bound = float(np.sqrt(3.0 * scale / ((fan_in + fan_out) / 2.0)))
+    return (torch.rand(*shape, generator=gen) * 2.0 - 1.0) * bound
+
+
+@BackboneRegistry.register("ncsnpp")
+class NCSNpp(nn.Module):
+    """NCSN++ with biggan res-blocks, FIR resampling, progressive 'output_skip' / 'input_skip' (sum), Fourier
+    time embedding and bottleneck attention -- the configuration family of the predict path
+    (reference ncsnpp.py:42-69 defaults)."""
+
+    supports_hip = True
+
+    def __init__(self, nf=128, ch_mult: Sequence[int] = (1, 2, 2, 2), num_res_blocks=1, input_channels=4,
+                 fourier_scale=16, init_scale=0.0, image_size=256, precision="bf16", n_freq=None, **unsupported):
+        super().__init__()
+        fixed = dict(scale_by_sigma=True, nonlinearity="swish", attn_resolutions=(0,), resamp_with_conv=True,
+                     conditional=True, fir=True, fir_kernel=[1, 3, 3, 1], skip_rescale=True, resblock_type="biggan",
+                     progressive="output_skip", progressive_input="input_skip", progressive_combine="sum",
+                     embedding_type="fourier", spatial_channels=1, dropout=0.0, centered=False, discriminative=False)
+        for k, v in unsupported.items():
+            if k in fixed and (list(v) if isinstance(v, (list, tuple)) else v) != (list(fixed[k]) if isinstance(fixed[k], (list, tuple)) else fixed[k]):
+                raise NotImplementedError(f"NCSNpp(HIP): option {k}={v!r} is outside the predict-path configuration ({fixed[k]!r})")
+        if input_channels != 4:
+            raise NotImplementedError("NCSNpp(HIP): only condition='noisy' (input_channels=4) is implemented")
+        self.nf, self.ch_mult, self.num_res_blocks = nf, tuple(ch_mult), num_res_blocks
+        self.input_channels, self.precision, self.n_freq = input_channels, precision, n_freq
+        gen = torch.Generator().manual_seed(torch.initial_seed() & 0x7FFFFFFF)
+        shapes = ncsnpp_param_shapes(nf=nf, ch_mult=ch_mult, num_res_blocks=num_res_blocks, input_channels=input_channels)
+        self.output_layer = _Holder()
+        self.all_modules = nn.ModuleList()
+        zero_init = ("Conv_1.weight", "NIN_3.W")          # init_scale=0 layers (reference layerspp.py:74,273)
+        for key, shape in shapes.items():
+            parts = key.split(".")
+            if len(shape) == 1:
+                if key == "all_modules.0.W":
+                    val = torch.randn(shape, generator=gen) * fourier_scale
+                elif parts[-1] == "weight":
+                    val = torch.ones(shape)
+                else:
+                    val = torch.zeros(shape)
+            else:
+                pyramid_conv = len(parts) == 3 and shape[0] == input_channels and len(shape) == 4 and shape[2] == 3
+                scale = init_scale if (key.endswith(zero_init) or pyramid_conv) else (0.1 if ".NIN_" in key else 1.0)
+                val = _fan_avg_uniform(shape, scale, gen)
+            node = self
+            if parts[0] == "all_modules":
+                idx = int(parts[1])
+                while len(self.all_modules) <= idx:
+                    self.all_modules.append(_Holder())
+                node = self.all_modules[idx]
+                parts = parts[2:]
+            for p in parts[:-1]:
+                if not hasattr(node, p):
+                    node.add_module(p, _Holder())
+                node = getattr(node, p)
+            node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=False))
+        self._engine = None
+        self._engine_dirty = True
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_engine_dirty", True))
+
+    # -- engine management --------------------------------------------------------------------------------
+    def engine(self, n_freq: int, device=None):
+        from ...hip_engine import HipScoreEngine
+        if self._engine is None or self._engine.n_freq != n_freq:
+            self._engine = HipScoreEngine(nf=self.nf, ch_mult=self.ch_mult, num_res_blocks=self.num_res_blocks,
+                                          n_freq=n_freq, precision=self.precision,
+                                          device=None if device is None else torch.device(device).index)
+            self._engine_dirty = True
+        if self._engine_dirty:
+            self._engine.load_state_dict(self.state_dict())
+            self._engine_dirty = False
+        return self._engine
+
+    def refresh_weights(self):
+        """Call after modifying parameters in place (``load_state_dict`` is tracked automatically)."""
+        self._engine_dirty = True
+
+    def forward(self, x: torch.Tensor, time_cond: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 4 or x.shape[1] != 2:
+            raise ValueError("expected complex input [B, 2, F, T'] = cat([x_t, Y], dim=1)")
+        if not x.is_cuda:
+            from ...hip_engine import UseHipError
+            raise UseHipError("NCSN++ (HIP) needs CUDA/ROCm tensors: the score network has no CPU implementation")
+        eng = self.engine(x.shape[2], x.device)
+        # the library returns the score (-network output); the backbone contract is the raw output
+        return -eng.score(x[:, 0:1], x[:, 1:2], time_cond)
+
+
+@BackboneRegistry.register("ncsnpplarge")
+class NCSNppLarge(NCSNpp):
+    """nf=128, ch_mult=(1,1,2,2,2,2,2), 2 res-blocks per level, ~65 M parameters (reference ncsnpp.py:504-518)."""
+
+    def __init__(self, **kwargs):
+        super().__init__(nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, **kwargs)
+
+
+# explicit names for configs that want to state the implementation
+BackboneRegistry.register("ncsnpp_hip")(NCSNpp)
+BackboneRegistry.register("ncsnpplarge_hip")(NCSNppLarge)

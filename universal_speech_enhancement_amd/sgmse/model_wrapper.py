@@ -1,0 +1,162 @@
+"""``ScoreModel`` with the constructor keys, methods and batch-dict contract of the reference's
+``sgmse/model_wrapper.py:23-329`` -- STFT glue in core torch (as the reference: ``torch.stft`` :116-122), the
+score network and the whole reverse-SDE loop in libuse_hip.so.
+
+Additions over the reference (all optional, defaults reproduce stock behaviour): ``precision`` ("bf16" | "fp32"),
+``use_graph``, and ``noise`` / ``seed`` keywords on ``sample`` / ``enhance`` for reproducible runs.
+Training (``train_step``) is outside this library's scope and raises.
+"""
+from __future__ import annotations
+
+from math import ceil
+
+import torch
+import torch.nn as nn
+
+from . import sampling
+from .backbones import BackboneRegistry
+from .sdes import SDERegistry
+from .util.other import pad_spec
+
+
+def get_window(window_type, window_length):
+    if window_type == "sqrthann":
+        return torch.sqrt(torch.hann_window(window_length, periodic=True))
+    if window_type == "hann":
+        return torch.hann_window(window_length, periodic=True)
+    raise NotImplementedError(f"Window type {window_type} not implemented!")
+
+
+class ScoreModel(nn.Module):
+    supports_fused_sampler = True
+
+    def __init__(self, backbone: str = "ncsnpp", sde: str = "ouve", t_eps: float = 3e-2, mode="regen-joint-training",
+                 condition="both", loss_type: str = "mse", n_fft=510, hop_length=128, num_frames=256, window="hann",
+                 spec_factor=0.15, spec_abs_exponent=0.5, sde_input="denoised", predictor="reverse_diffusion",
+                 corrector="none", precision="bf16", use_graph=True):
+        super().__init__()
+        input_channels = 6 if condition == "both" else 4
+        self.score_net = (BackboneRegistry.get_by_name(backbone)(input_channels=input_channels, precision=precision)
+                          if backbone != "none" else None)
+        self.sde = SDERegistry.get_by_name(sde)()
+        self.t_eps, self.condition, self.mode, self.loss_type = t_eps, condition, mode, loss_type
+        self.n_fft, self.hop_length, self.num_frames = n_fft, hop_length, num_frames
+        self.window = get_window(window, n_fft)
+        self.windows = {}
+        self.spec_factor, self.spec_abs_exponent = spec_factor, spec_abs_exponent
+        self.target_len = (num_frames - 1) * hop_length
+        self.sde_input, self.predictor, self.corrector = sde_input, predictor, corrector
+        self.precision, self.use_graph = precision, use_graph
+
+    # ---- STFT glue (reference :92-122) -------------------------------------------------------------------
+    def spec_fwd(self, spec):
+        if self.spec_abs_exponent != 1:
+            spec = spec.abs() ** self.spec_abs_exponent * torch.exp(1j * spec.angle())
+        return spec * self.spec_factor
+
+    def spec_back(self, spec):
+        spec = spec / self.spec_factor
+        if self.spec_abs_exponent != 1:
+            spec = spec.abs() ** (1 / self.spec_abs_exponent) * torch.exp(1j * spec.angle())
+        return spec
+
+    def _get_window(self, x):
+        w = self.windows.get(x.device)
+        if w is None:
+            w = self.windows[x.device] = self.window.to(x.device)
+        return w
+
+    def stft(self, sig):
+        return torch.stft(sig, n_fft=self.n_fft, hop_length=self.hop_length, window=self._get_window(sig), center=True,
+                          return_complex=True)
+
+    def istft(self, spec, length=None):
+        return torch.istft(spec, n_fft=self.n_fft, hop_length=self.hop_length, window=self._get_window(spec), center=True,
+                           length=length)
+
+    # ---- score function (reference :135-145) -------------------------------------------------------------
+    def forward_score(self, x, t, score_conditioning, sde_input):
+        dnn_input = torch.cat([x] + list(score_conditioning), dim=1)
+        return -self.score_net(dnn_input, t)
+
+    def forward(self, x, t, score_conditioning, sde_input):
+        return self.forward_score(x, t, score_conditioning, sde_input)
+
+    def train_step(self, batch):
+        raise NotImplementedError("training is outside the scope of the MI355X sampling library (inference only)")
+
+    # ---- samplers (reference :210-260) -------------------------------------------------------------------
+    def fused_sample(self, y, N, predictor, corrector, corrector_steps, snr, t_eps, noise=None, seed=0, use_graph=True):
+        """Whole PC loop inside libuse_hip.so (``use_sample``)."""
+        eng = self.score_net.engine(y.shape[2], y.device)
+        eng.plan(y.shape[0], y.shape[3])
+        eng.set_sampler(N, predictor, corrector, corrector_steps, snr, t_eps, use_graph=use_graph)
+        return eng.sample(y, noise=noise, seed=seed)
+
+    def get_pc_sampler(self, predictor_name, corrector_name, y, N=None, minibatch=None, **kwargs):
+        N = self.sde.N if N is None else N
+        sde = self.sde.copy()
+        sde.N = N
+        kwargs = {"eps": self.t_eps, "use_graph": self.use_graph, **kwargs}
+        if minibatch is None:
+            return sampling.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y, **kwargs)
+        M = y.shape[0]
+        cond = kwargs.pop("conditioning", None)
+
+        def batched_sampling_fn():
+            samples, ns = [], []
+            for i in range(int(ceil(M / minibatch))):
+                y_mini = y[i * minibatch:(i + 1) * minibatch]
+                c_mini = None if cond is None else [y_mini if c is y else c[i * minibatch:(i + 1) * minibatch] for c in cond]
+                sample, n = sampling.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y_mini,
+                                                    conditioning=c_mini, **kwargs)()
+                samples.append(sample); ns.append(n)
+            return torch.cat(samples, dim=0), ns
+        return batched_sampling_fn
+
+    def get_ode_sampler(self, *args, **kwargs):
+        raise NotImplementedError("the probability-flow ODE sampler (scipy RK45 host solver) is not on the predict path")
+
+    def _spectrogram(self, y):
+        return pad_spec(self.spec_fwd(self.stft(y)).unsqueeze(1))
+
+    def sample(self, batch, sampler_type="pc", N=50, corrector_steps=1, snr=0.5, noise=None, seed=0):
+        """Reference :262-329: adds ``batch['enhanced']`` (float32 [B, L]) for condition / sde_input 'noisy'."""
+        y = batch["perturbed"]
+        T_orig = y.size(1)
+        Y = self._spectrogram(y)
+        if self.condition != "noisy":
+            raise NotImplementedError(f"Don't know the conditioning you have wished for: {self.condition}")
+        if self.sde_input != "noisy":
+            raise NotImplementedError(f"Don't know the sde input you have wished for: {self.sde_input}")
+        if sampler_type != "pc":
+            raise NotImplementedError(f"{sampler_type} is not a valid sampler type!")
+        sampler = self.get_pc_sampler(self.predictor, self.corrector, Y, N=N, corrector_steps=corrector_steps, snr=snr,
+                                      intermediate=False, conditioning=[Y], noise=noise, seed=seed)
+        sample, nfe = sampler()
+        batch["enhanced"] = self.istft(self.spec_back(sample.squeeze(1)), T_orig)
+        return batch
+
+    @torch.no_grad()
+    def enhance(self, y, sampler_type="pc", predictor="reverse_diffusion", corrector="ald", N=50, corrector_steps=1,
+                snr=0.5, timeit=False, return_stft=False, noise=None, seed=0, sr=24000, **kwargs):
+        """One-call enhancement of noisy speech ``y`` [1, L] -- keyword surface of the legacy
+        ``ScoreModel.enhance`` (reference ``sgmse/model.py:351-402``)."""
+        import time
+        start = time.time()
+        T_orig = y.size(1)
+        norm_factor = y.abs().max().item()
+        y = y / norm_factor
+        if not y.is_cuda:
+            y = y.cuda()
+        Y = self._spectrogram(y)
+        if sampler_type != "pc":
+            raise NotImplementedError(f"{sampler_type} is not a valid sampler type!")
+        sample, nfe = self.get_pc_sampler(predictor, corrector, Y, N=N, corrector_steps=corrector_steps, snr=snr,
+                                          intermediate=False, conditioning=[Y], noise=noise, seed=seed)()
+        if return_stft:
+            return sample.squeeze(), Y.squeeze(), T_orig, norm_factor
+        x_hat = (self.istft(self.spec_back(sample.squeeze(1)), T_orig) * norm_factor).squeeze().cpu()
+        if timeit:
+            return x_hat, nfe, (time.time() - start) / (len(x_hat) / sr)
+        return x_hat
