@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -111,6 +112,7 @@ struct use_handle {
     static constexpr int SDE_MAX_B = 1024, SDE_BLOCKS = 128;
     // per-launch HIP-event profiling of the dominant conv kernel (use_profile_score)
     bool profile = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_flops;
+    std::vector<std::string> prof_desc;
     // introspection
     bool dry = false;
     std::map<std::string, Act> debug;
@@ -341,6 +343,8 @@ struct Fwd {
             (void)hipEventRecord(e1, s);
             h->prof_events.push_back({e0, e1});
             h->prof_flops.push_back(2.0 * h->B * a.H * a.W * (double)w.cout * w.cin * w.ntaps);
+            char d[160]; snprintf(d, sizeof d, "%-28s H=%3d W=%3d Cin=%3d Cout=%3d taps=%d gn=%d res=%d", w.wname.c_str(), a.H, a.W, w.cin, w.cout, w.ntaps, coef != nullptr, res != nullptr);
+            h->prof_desc.push_back(d);
         } else {
             launch_conv(p, s);
         }
@@ -716,7 +720,8 @@ int use_profile_score(use_handle* h, const void* x, const void* y, const float* 
     int rc = check_ready(h); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t t0, t1; HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
-    h->profile = true; h->prof_events.clear(); h->prof_flops.clear();
+    h->profile = true; h->prof_events.clear(); h->prof_flops.clear(); h->prof_desc.clear();
+    const bool verbose = getenv("USE_HIP_PROFILE_VERBOSE") != nullptr;
     HIPCHK(hipEventRecord(t0, s));
     rc = use_score(h, x, y, t, out, stream);
     h->profile = false;
@@ -727,6 +732,7 @@ int use_profile_score(use_handle* h, const void* x, const void* y, const float* 
     for (size_t i = 0; i < h->prof_events.size(); ++i) {
         float e = 0.f; HIPCHK(hipEventElapsedTime(&e, h->prof_events[i].first, h->prof_events[i].second));
         ms += e; fl += h->prof_flops[i];
+        if (verbose) fprintf(stderr, "[use_profile] %s  %8.3f ms  %7.1f TFLOP/s\n", h->prof_desc[i].c_str(), e, h->prof_flops[i] / e / 1e9);
         (void)hipEventDestroy(h->prof_events[i].first); (void)hipEventDestroy(h->prof_events[i].second);
     }
     float tot = 0.f; HIPCHK(hipEventElapsedTime(&tot, t0, t1));
