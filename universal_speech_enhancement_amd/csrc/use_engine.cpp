@@ -49,7 +49,7 @@ struct ConvW { std::string wname, bname; int cin = 0, cout = 0, cout_pad = 0, nt
                bool nin = false; size_t w_off = 0, b_off = 0; };
 struct GNW { std::string prefix; int C = 0; size_t g_off = 0, b_off = 0; };
 struct ResW { int idx = 0, in_ch = 0, out_ch = 0; bool up = false, down = false, has_c2 = false;
-              GNW gn0, gn1; ConvW c0, c1, c2; int dense_row0 = 0; };
+              GNW gn0, gn1; ConvW c0, c1, c2; int dense_row0 = 0; size_t b12_off = 0; };   // b12 = Conv_1.bias + Conv_2.bias
 struct CombineW { int idx = 0, C = 0; size_t w_off = 0, b_off = 0; };      // conv1x1 4->C, fp32 [C][4]
 struct AttnW { int idx = 0, C = 0; GNW gn; ConvW q, k, v, o; };
 struct PyrW { GNW gn; ConvW conv; };
@@ -233,7 +233,10 @@ static int build_arch(use_handle* h) {
     h->l2w_off = take((size_t)4 * nf * 4 * nf * 4); h->l2b_off = take((size_t)4 * nf * 4);
     h->dense_w_off = take((size_t)h->dense_rows * 4 * nf * 4); h->dense_b_off = take((size_t)h->dense_rows * 4);
     lay_conv(h->conv_in);
-    for (auto& r : h->res) { lay_gn(r.gn0); lay_conv(r.c0); lay_gn(r.gn1); lay_conv(r.c1); if (r.has_c2) lay_conv(r.c2); }
+    for (auto& r : h->res) {
+        lay_gn(r.gn0); lay_conv(r.c0); lay_gn(r.gn1); lay_conv(r.c1);
+        if (r.has_c2) { lay_conv(r.c2); r.b12_off = take((size_t)r.out_ch * 4); }
+    }
     for (auto& cb : h->combines) { cb.w_off = take((size_t)cb.C * 4 * 4); cb.b_off = take((size_t)cb.C * 4); }
     lay_gn(h->attn.gn); lay_conv(h->attn.q); lay_conv(h->attn.k); lay_conv(h->attn.v); lay_conv(h->attn.o);
     for (auto& p : h->pyrs) { lay_gn(p.gn); lay_conv(p.conv); }
@@ -279,8 +282,13 @@ static int pack_all(use_handle* h, char* blob) {
     pack_conv(h, h->conv_in, blob);
     for (const auto& r : h->res) {
         pack_gn(h, r.gn0, blob); pack_conv(h, r.c0, blob); pack_gn(h, r.gn1, blob); pack_conv(h, r.c1, blob);
-        if (r.has_c2) pack_conv(h, r.c2, blob);
         const std::string p = "all_modules." + std::to_string(r.idx);
+        if (r.has_c2) {
+            pack_conv(h, r.c2, blob);
+            const auto& b1 = h->host_w.at(p + ".Conv_1.bias"); const auto& b2 = h->host_w.at(p + ".Conv_2.bias");
+            float* d = (float*)(blob + r.b12_off);
+            for (int i = 0; i < r.out_ch; ++i) d[i] = b1[i] + b2[i];
+        }
         memcpy(blob + h->dense_w_off + (size_t)r.dense_row0 * 4 * nf * 4, h->host_w.at(p + ".Dense_0.weight").data(),
                (size_t)r.out_ch * 4 * nf * 4);
         memcpy(blob + h->dense_b_off + (size_t)r.dense_row0 * 4, h->host_w.at(p + ".Dense_0.bias").data(),
@@ -323,13 +331,18 @@ struct Fwd {
     }
 
     Act conv(const Act& a, const Act* a2, const float* coef, int act, const ConvW& w, const float* temb,
-             const Act* res, float scale, const float* pyr, const CombineW* cb, int out_dtype, bool stats) {
+             const Act* res, float scale, const float* pyr, const CombineW* cb, int out_dtype, bool stats,
+             const Act* sx0 = nullptr, const Act* sx1 = nullptr, const ConvW* w2 = nullptr, size_t bias_off = 0) {
         Act o = new_act(w.cout, a.H, a.W, out_dtype, stats);
-        h->flops += 2.0 * h->B * a.H * a.W * (double)w.cout * w.cin * w.ntaps;
+        double fl = 2.0 * h->B * a.H * a.W * (double)w.cout * w.cin * w.ntaps;
+        if (w2) fl += 2.0 * h->B * a.H * a.W * (double)w2->cout * w2->cin;
+        h->flops += fl;
         if (h->dry) return o;
         ConvArgs p{};
         p.src0 = a.p; p.C0 = a.C; p.src1 = a2 ? a2->p : nullptr; p.C1 = a2 ? a2->C : 0; p.in_dtype = a.dtype;
-        p.coef = coef; p.act = act; p.w = h->blob + w.w_off; p.cout_pad = w.cout_pad; p.bias = W<float>(w.b_off);
+        p.coef = coef; p.act = act; p.w = h->blob + w.w_off; p.cout_pad = w.cout_pad;
+        p.bias = W<float>(w2 ? bias_off : w.b_off);
+        if (w2) { p.x0 = sx0->p; p.XC0 = sx0->C; p.x1 = sx1 ? sx1->p : nullptr; p.XC1 = sx1 ? sx1->C : 0; p.w2 = h->blob + w2->w_off; }
         p.temb = temb; p.temb_bstride = temb_bstride;
         p.res = res ? res->p : nullptr; p.out_scale = scale;
         p.pyr = pyr; p.w4 = cb ? W<float>(cb->w_off) : nullptr; p.b4 = cb ? W<float>(cb->b_off) : nullptr;
@@ -342,8 +355,8 @@ struct Fwd {
             launch_conv(p, s);
             (void)hipEventRecord(e1, s);
             h->prof_events.push_back({e0, e1});
-            h->prof_flops.push_back(2.0 * h->B * a.H * a.W * (double)w.cout * w.cin * w.ntaps);
-            char d[160]; snprintf(d, sizeof d, "%-28s H=%3d W=%3d Cin=%3d Cout=%3d taps=%d gn=%d res=%d", w.wname.c_str(), a.H, a.W, w.cin, w.cout, w.ntaps, coef != nullptr, res != nullptr);
+            h->prof_flops.push_back(fl);
+            char d[160]; snprintf(d, sizeof d, "%-28s H=%3d W=%3d Cin=%3d Cout=%3d taps=%d gn=%d res=%d sc=%d", w.wname.c_str(), a.H, a.W, w.cin, w.cout, w.ntaps, coef != nullptr, res != nullptr, w2 ? w2->cin : 0);
             h->prof_desc.push_back(d);
         } else {
             launch_conv(p, s);
@@ -357,22 +370,25 @@ struct Fwd {
         const float* temb = tembias + r.dense_row0;
         float* coef0 = gn_coef(x, skip, r.gn0);
         const int dt = h->act_dtype;
-        Act hcur, xres;
+        Act hcur, xr;
+        const Act* sx0 = &x; const Act* sx1 = skip;          // inputs of the 1x1 shortcut (Conv_2)
         if (r.up || r.down) {
             const int H2 = r.up ? x.H * 2 : x.H / 2, W2 = r.up ? x.W * 2 : x.W / 2;
-            Act hr = new_act(x.C, H2, W2, dt, false), xr = new_act(x.C, H2, W2, dt, false);
+            Act hr = new_act(x.C, H2, W2, dt, false);
+            xr = new_act(x.C, H2, W2, dt, false);
             if (!h->dry) {
                 if (r.up) launch_fir_up2(x.p, dt, coef0, 1, hr.p, xr.p, h->B, x.H, x.W, x.C, s);
                 else      launch_fir_down2(x.p, dt, coef0, 1, hr.p, xr.p, h->B, x.H, x.W, x.C, s);
             }
             hcur = conv(hr, nullptr, nullptr, 0, r.c0, temb, nullptr, 1.f, nullptr, nullptr, dt, true);
-            xres = conv(xr, nullptr, nullptr, 0, r.c2, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
+            sx0 = &xr; sx1 = nullptr;
         } else {
             hcur = conv(x, skip, coef0, 1, r.c0, temb, nullptr, 1.f, nullptr, nullptr, dt, true);
-            xres = r.has_c2 ? conv(x, skip, nullptr, 0, r.c2, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false) : x;
         }
         float* coef1 = gn_coef(hcur, nullptr, r.gn1);
-        return conv(hcur, nullptr, coef1, 1, r.c1, nullptr, &xres, rs, pyr, cb, dt, true);
+        if (r.has_c2)   // Conv_1 and the Conv_2 shortcut accumulate into the same MFMA tile (one K loop)
+            return conv(hcur, nullptr, coef1, 1, r.c1, nullptr, nullptr, rs, pyr, cb, dt, true, sx0, sx1, &r.c2, r.b12_off);
+        return conv(hcur, nullptr, coef1, 1, r.c1, nullptr, &x, rs, pyr, cb, dt, true);
     }
 
     // AttnBlockpp.forward (reference layerspp.py:77-93)

@@ -17,7 +17,7 @@ inline int tiles_per_image(int H, int W) { return ((H + TILE_H - 1) / TILE_H) * 
 // Implicit-GEMM convolution (3x3 pad 1, or 1x1) with fused prologue / epilogue.
 //   in   = concat(src0[C0], src1[C1]) along channels, optional per-(b, channel) affine
 //          (GroupNorm folded to a*x+b) followed by optional SiLU, zero outside the image
-//   out  = ((conv(in) + bias + temb[b]) + res) * out_scale + (w4 . pyr + b4)
+//   out  = ((conv(in) + conv1x1(x) + bias + temb[b]) + res) * out_scale + (w4 . pyr + b4)
 //   stats[b][tile][cout][2] = per-tile per-channel (sum, sum of squares) of the stored values
 struct ConvArgs {
     const void* src0; const void* src1; int C0; int C1; int in_dtype;
@@ -25,6 +25,9 @@ struct ConvArgs {
     int act;                // 0: none, 1: SiLU (after the affine)
     const void* w;          // packed [ntaps][CoutPad][C0+C1] in in_dtype
     int cout_pad;
+    // optional second K segment: + conv1x1(concat(x0[XC0], x1[XC1])) with weights w2 [1][CoutPad][XC0+XC1]
+    // (the res-block shortcut Conv_2 fused into Conv_1; raw input, no affine / activation)
+    const void* x0; const void* x1; int XC0; int XC1; const void* w2;
     const float* bias;      // [Cout] or null
     const float* temb;      // [B or 1][temb_stride] slice start for this conv, or null
     int temb_bstride;       // elements between batch rows (0: shared by the batch)

@@ -110,8 +110,16 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
     constexpr bool ACC = sizeof(TIN) == 4;                // fp32 parity mode: accurate SiLU
     static_assert(WM * WN == 4 && MW % 32 == 0 && NW % 32 == 0 && CK % MF::KM == 0 && PARTS >= 1, "tiling");
 
-    __shared__ __attribute__((aligned(16))) char s_halo[HALO_MAX * ROWB];
-    __shared__ __attribute__((aligned(16))) char s_w[2][BN * ROWB];
+    // one LDS object, carved: [halo tile][2 weight slabs]; the epilogue re-uses it as [4 waves x staging][stats]
+    constexpr int HALO_BYTES = HALO_MAX * ROWB, W_BYTES = BN * ROWB;
+    constexpr int STG_LD = NW + 4;                                   // fp32 staging row (padded)
+    constexpr int STG_WAVE = 32 * STG_LD * 4;                        // one 32-pixel x NW tile per wave
+    constexpr int EPI_BYTES = 4 * STG_WAVE + WM * BN * 2 * 4;
+    constexpr int MAIN_BYTES = HALO_BYTES + 2 * W_BYTES;
+    constexpr int SMEM_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    char* const s_halo = smem;
+    char* const s_w0 = smem + HALO_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -123,7 +131,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
     const int HW_ = TILE_W + 2 * pad, HH_ = TILE_H + 2 * pad;
     const int Ctot = p.C0 + p.C1;
     const int nchunks = Ctot / CK;
-    const int nit = nchunks * p.ntaps;
+    const int nit1 = nchunks * p.ntaps;                   // segment 0: taps x chunks of the (normalised) input
+    const int XCtot = p.XC0 + p.XC1;
+    const int nit = nit1 + XCtot / CK;                    // segment 1: 1x1 shortcut over the raw block input
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -144,14 +154,23 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
     for (int j = 0; j < TN; ++j)
         b_base[j] = (wn * NW + j * 32 + (lane & 31)) * ROWB + (lane >> 5) * MF::KPL * (int)sizeof(TIN);
 
-    auto stage_halo = [&](int chunk) {
-        const int c_glob = chunk * CK;
+    // stage the halo tile of the channel chunk that iteration `it` starts
+    auto stage_halo = [&](int it) {
+        const bool seg1 = it >= nit1;
+        const int c_glob = (seg1 ? it - nit1 : it / p.ntaps) * CK;
         const TIN* src; int Cs, c_loc;
-        if (c_glob < p.C0) { src = (const TIN*)p.src0; Cs = p.C0; c_loc = c_glob; }
-        else               { src = (const TIN*)p.src1; Cs = p.C1; c_loc = c_glob - p.C0; }
+        if (!seg1) {
+            if (c_glob < p.C0) { src = (const TIN*)p.src0; Cs = p.C0; c_loc = c_glob; }
+            else               { src = (const TIN*)p.src1; Cs = p.C1; c_loc = c_glob - p.C0; }
+        } else {
+            if (c_glob < p.XC0) { src = (const TIN*)p.x0; Cs = p.XC0; c_loc = c_glob; }
+            else                { src = (const TIN*)p.x1; Cs = p.XC1; c_loc = c_glob - p.XC0; }
+        }
+        const bool use_coef = p.coef && !seg1;
+        const bool use_act = p.act && !seg1;
         const int part = tid % PARTS;                      // constant per thread (256 % PARTS == 0)
         float ca[VEC], cb[VEC];
-        if (p.coef) {
+        if (use_coef) {
             const float* cf = p.coef + ((size_t)b * Ctot + c_glob + part * VEC) * 2;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) { ca[k] = cf[2 * k]; cb[k] = cf[2 * k + 1]; }
@@ -164,11 +183,11 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
             float v[VEC];
             if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
                 Vec16<TIN>::load(src + ((size_t)(b * p.H + gy) * p.W + gx) * Cs + c_loc + part * VEC, v);
-                if (p.coef) {
+                if (use_coef) {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) v[k] = fmaf(v[k], ca[k], cb[k]);
                 }
-                if (p.act) {
+                if (use_act) {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) v[k] = silu_f<ACC>(v[k]);
                 }
@@ -186,19 +205,21 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
     if (WPT > (Q)) {                                                                                           \
         const int idx = tid + (Q)*256;                                                                         \
         if (!WGUARD || idx < BN * PARTS)                                                                       \
-            DST = *reinterpret_cast<const uint4*>(wb_ + (size_t)(idx / PARTS) * Ctot + (idx % PARTS) * VEC);   \
+            DST = *reinterpret_cast<const uint4*>(wb_ + (size_t)(idx / PARTS) * wld_ + (idx % PARTS) * VEC);   \
     }
 #define USE_LOAD_W(IT)                                                                                         \
     {                                                                                                          \
-        const int chunk_ = (IT) / p.ntaps, tap_ = (IT)-chunk_ * p.ntaps;                                       \
-        const TIN* wb_ = (const TIN*)p.w + ((size_t)tap_ * p.cout_pad + n0) * Ctot + chunk_ * CK;             \
+        const bool seg1_ = (IT) >= nit1;                                                                       \
+        const int chunk_ = seg1_ ? (IT)-nit1 : (IT) / p.ntaps, tap_ = seg1_ ? 0 : (IT)-chunk_ * p.ntaps;       \
+        const int wld_ = seg1_ ? XCtot : Ctot;                                                                 \
+        const TIN* wb_ = (seg1_ ? (const TIN*)p.w2 : (const TIN*)p.w) + ((size_t)tap_ * p.cout_pad + n0) * wld_ + chunk_ * CK; \
         USE_LOAD_Q(0, wr0) USE_LOAD_Q(1, wr1) USE_LOAD_Q(2, wr2) USE_LOAD_Q(3, wr3)                            \
     }
 #define USE_STORE_Q(Q, SRC, BUF)                                                                               \
     if (WPT > (Q)) {                                                                                           \
         const int idx = tid + (Q)*256;                                                                         \
         if (!WGUARD || idx < BN * PARTS)                                                                       \
-            *reinterpret_cast<uint4*>(s_w[BUF] + (idx / PARTS) * ROWB + (idx % PARTS) * 16) = SRC;             \
+            *reinterpret_cast<uint4*>(s_w0 + (BUF)*W_BYTES + (idx / PARTS) * ROWB + (idx % PARTS) * 16) = SRC;             \
     }
 #define USE_STORE_W(BUF)                                                                                       \
     { USE_STORE_Q(0, wr0, BUF) USE_STORE_Q(1, wr1, BUF) USE_STORE_Q(2, wr2, BUF) USE_STORE_Q(3, wr3, BUF) }
@@ -209,12 +230,13 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
     __syncthreads();
 
     for (int it = 0; it < nit; ++it) {
-        const int chunk = it / p.ntaps, tap = it - chunk * p.ntaps;
+        const bool seg1 = it >= nit1;
+        const int tap = seg1 ? 4 : it % p.ntaps;          // the shortcut reads the centre tap of the halo tile
         const bool has_next = (it + 1 < nit);
         if (has_next) USE_LOAD_W(it + 1);
         const int dy = pad ? tap / 3 : 0, dx = pad ? tap - dy * 3 : 0;
         const char* ha = s_halo + (dy * HW_ + dx) * ROWB;
-        const char* wb = s_w[it & 1];
+        const char* wb = s_w0 + (it & 1) * W_BYTES;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             typename MF::frag af[TM], bf[TN];
@@ -229,67 +251,105 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
         }
         if (has_next) {
             USE_STORE_W((it + 1) & 1);
-            if (tap == p.ntaps - 1) {          // next iteration starts a new channel chunk: restage the halo
+            if (it + 1 >= nit1 || (it + 1) % p.ntaps == 0) {   // next iteration starts a new channel chunk
                 __syncthreads();
-                stage_halo(chunk + 1);
+                stage_halo(it + 1);
             }
         }
         __syncthreads();
     }
 
     // ------------------------------ epilogue ------------------------------
-    float st_s[TN], st_q[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
+    // Each wave transposes its accumulators through LDS (fp32, one 32-pixel x NW slab at a time) so that every lane
+    // then owns 16 contiguous output bytes of one pixel: residual loads and output stores are full 16-byte accesses
+    // (8 lanes = one pixel's 128-byte row segment) instead of 2-byte accesses scattered over two pixels.
+    constexpr int CH = 16 / (int)sizeof(TOUT);               // output channels per 16-byte chunk
+    constexpr int CPR = NW / CH;                             // chunks per staging row
+    constexpr int QN = 32 * CPR / 64;                        // chunks per lane per slab
+    static_assert(64 % CPR == 0 && QN >= 1, "epilogue chunking");
+    float* const stg = reinterpret_cast<float*>(smem + wave * STG_WAVE);
+    float* const red = reinterpret_cast<float*>(smem + 4 * STG_WAVE);     // [WM][BN][2]
     TOUT* out = (TOUT*)p.out;
     const TOUT* res = (const TOUT*)p.res;
+    float addv[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int co = n0 + wn * NW + j * 32 + (lane & 31);
-        const bool cok = co < p.Cout;
         float add = 0.f;
-        float w4v[4] = {0.f, 0.f, 0.f, 0.f}; float b4v = 0.f;
-        if (cok) {
+        if (co < p.Cout) {
             if (p.bias) add += p.bias[co];
             if (p.temb) add += p.temb[(size_t)b * p.temb_bstride + co];
-            if (p.pyr) {
-                const float4 wq = *reinterpret_cast<const float4*>(p.w4 + (size_t)co * 4);
-                w4v[0] = wq.x; w4v[1] = wq.y; w4v[2] = wq.z; w4v[3] = wq.w; b4v = p.b4[co];
-            }
         }
+        addv[j] = add;
+    }
+    const int ch = lane % CPR;                               // this lane's chunk column (constant over q)
+    const int co0 = n0 + wn * NW + ch * CH;
+    const bool cok = co0 < p.Cout;                           // Cout is a multiple of CH
+    float st_s[CH], st_q[CH];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+    for (int c = 0; c < CH; ++c) { st_s[c] = 0.f; st_q[c] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int m = wm * MW + i * 32 + row;
-                const int gy = ty0 + (m >> 4), gx = tx0 + (m & 15);
-                if (cok && gy < p.H && gx < p.W) {
-                    const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
-                    float v = acc[i][j][r] + add;
-                    if (res) v += to_f(res[pix * p.Cout + co]);
-                    v *= p.out_scale;
-                    if (p.pyr) {
-                        const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
-                        v += b4v + w4v[0] * pq.x + w4v[1] * pq.y + w4v[2] * pq.z + w4v[3] * pq.w;
+                stg[row * STG_LD + j * 32 + (lane & 31)] = acc[i][j][r] + addv[j];
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            const int row = (q * 64 + lane) / CPR;
+            const int m = wm * MW + i * 32 + row;
+            const int gy = ty0 + (m >> 4), gx = tx0 + (m & 15);
+            float v[CH];
+#pragma unroll
+            for (int c4 = 0; c4 < CH / 4; ++c4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(stg + row * STG_LD + ch * CH + c4 * 4);
+                v[c4 * 4] = t4.x; v[c4 * 4 + 1] = t4.y; v[c4 * 4 + 2] = t4.z; v[c4 * 4 + 3] = t4.w;
+            }
+            if (cok && gy < p.H && gx < p.W) {
+                const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+                if (res) {
+                    float rv[CH];
+                    Vec16<TOUT>::load(res + pix * p.Cout + co0, rv);
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) v[c] += rv[c];
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) v[c] *= p.out_scale;
+                if (p.pyr) {
+                    const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const float4 wq = *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4);
+                        v[c] += p.b4[co0 + c] + wq.x * pq.x + wq.y * pq.y + wq.z * pq.z + wq.w * pq.w;
                     }
-                    const TOUT o = from_f<TOUT>(v);
-                    out[pix * p.Cout + co] = o;
-                    const float vr = to_f(o);
-                    st_s[j] += vr; st_q[j] += vr * vr;
+                }
+                const uint4 packed = Vec16<TOUT>::pack(v);
+                *reinterpret_cast<uint4*>(out + pix * p.Cout + co0) = packed;
+                if (p.stats) {
+                    float vr[CH];
+                    Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&packed), vr);   // statistics of the stored values
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) { st_s[c] += vr[c]; st_q[c] += vr[c] * vr[c]; }
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
     if (p.stats) {
-        float* red = reinterpret_cast<float*>(s_halo);     // [WM][BN][2]; all LDS reads finished (loop-end sync)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s = st_s[j] + __shfl_xor(st_s[j], 32);
-            float q = st_q[j] + __shfl_xor(st_q[j], 32);
-            if (lane < 32) {
-                const int cl = wn * NW + j * 32 + lane;
-                red[(wm * BN + cl) * 2] = s; red[(wm * BN + cl) * 2 + 1] = q;
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) { st_s[c] += __shfl_xor(st_s[c], o); st_q[c] += __shfl_xor(st_q[c], o); }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int cl = wn * NW + ch * CH + c;
+                red[(wm * BN + cl) * 2] = st_s[c]; red[(wm * BN + cl) * 2 + 1] = st_q[c];
             }
         }
         __syncthreads();
