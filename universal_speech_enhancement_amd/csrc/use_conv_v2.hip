@@ -1,0 +1,420 @@
+// conv_v2_kernel: software-pipelined implicit-GEMM 3x3 convolution for the large feature maps (the kernel that carries
+// >90 % of the path's FLOPs).  Same arithmetic and argument struct as conv_kernel (use_kernels.hip), different schedule:
+//
+//   * one workgroup = 8 waves (4 along pixels x 2 along output channels) computes a 16x16-pixel x 128-channel tile,
+//     one workgroup per CU (LDS: 2 halo buffers + 2 weight slabs = 130 KB of 160 KB);
+//   * the halo tile of the NEXT 64-channel chunk is loaded, GroupNorm+SiLU-transformed and written to the second LDS
+//     buffer piece by piece behind the MFMAs of the current chunk's taps (no exposed restaging);
+//   * weights are prefetched two (tap, chunk) iterations ahead in registers, double-buffered in LDS; one barrier per
+//     iteration (16 MFMAs per wave);
+//   * workgroups are re-ordered so that each XCD (private L2) works on a contiguous band of tiles.
+//
+// Segment 1 (the fused 1x1 shortcut of a res-block, raw input, centre tap only) streams 4 raw pieces per thread per
+// iteration through the same double buffer.
+#include "use_kernels.h"
+#include "use_device.h"
+
+#include <cstdlib>
+
+namespace use {
+
+constexpr int V2_T = 16;                      // tile edge (pixels)
+constexpr int V2_HE = V2_T + 2;               // halo edge
+constexpr int V2_HALO = V2_HE * V2_HE;        // 324 halo pixels
+constexpr int V2_BN = 128;
+
+// GroupNorm affine + SiLU on one 16-byte piece; `mask` = 0 zeroes it (conv zero padding / outside the image)
+template <typename TIN, bool ACT>
+DEVI uint4 v2_transform(const uint4 raw, const unsigned mask, const float (&ca)[16 / sizeof(TIN)],
+                        const float (&cb)[16 / sizeof(TIN)]) {
+    constexpr int VEC = 16 / sizeof(TIN);
+    float v[VEC];
+    Vec16<TIN>::load(reinterpret_cast<const TIN*>(&raw), v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        v[k] = fmaf(v[k], ca[k], cb[k]);
+        if (ACT) {
+            if (sizeof(TIN) == 4) v[k] = v[k] / (1.0f + expf(-v[k]));        // fp32 parity mode: accurate
+            else v[k] = v[k] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[k] * -1.44269504088896341f));
+        }
+    }
+    uint4 o = Vec16<TIN>::pack(v);
+    o.x &= mask; o.y &= mask; o.z &= mask; o.w &= mask;
+    return o;
+}
+
+template <typename TIN, typename TOUT, int CK, bool ACT>
+__global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
+    typedef Mfma<TIN> MF;
+    constexpr int VEC = 16 / sizeof(TIN);
+    constexpr int PARTS = CK / VEC;
+    constexpr int ROWB = CK * (int)sizeof(TIN) + 16;
+    constexpr int BN = V2_BN, WM = 4, WN = 2, MW = 64, NW = 64, TM = 2, TN = 2;
+    constexpr int KSTEPS = CK / MF::KM;
+    constexpr int HALO_BYTES = V2_HALO * ROWB, W_BYTES = BN * ROWB;
+    constexpr int MAIN_BYTES = 2 * HALO_BYTES + 2 * W_BYTES;
+    constexpr int NPIECE = V2_HALO * PARTS;                 // 16-byte pieces per halo chunk (2592)
+    constexpr int PIECE_ITERS = (NPIECE + 511) / 512;       // taps that carry one piece per thread (6)
+    static_assert(PARTS == 8 && 512 % PARTS == 0 && PIECE_ITERS <= 8, "v2 staging assumes 128-byte chunk rows");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [2][HALO_BYTES] halo tiles, [2][W_BYTES] weight slabs, [512][16] dummy slots (threads without a piece)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int b = blockIdx.z;
+    // XCD-aware order: dispatch is round-robin over the 8 XCDs; give each XCD a contiguous band of tiles
+    int tile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int tiles_x = (p.W + V2_T - 1) / V2_T;
+    const int ty0 = (tile / tiles_x) * V2_T, tx0 = (tile % tiles_x) * V2_T;
+    const int n0 = blockIdx.y * BN;
+    const int Ctot = p.C0 + p.C1;
+    const int nchunks = Ctot / CK;
+    const int XCtot = p.XC0 + p.XC1;
+    const int nchunks2 = XCtot / CK;
+    const int part = tid & (PARTS - 1);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int a_base[TM], b_base[TN];                              // LDS byte offsets of this lane's fragments
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = wm * MW + i * 32 + (lane & 31);
+        a_base[i] = ((m >> 4) * V2_HE + (m & 15)) * ROWB + (lane >> 5) * MF::KPL * (int)sizeof(TIN);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        b_base[j] = 2 * HALO_BYTES + (wn * NW + j * 32 + (lane & 31)) * ROWB + (lane >> 5) * MF::KPL * (int)sizeof(TIN);
+
+    // ---- segment-0 halo pieces: this thread's piece j (0..5) of every chunk ------------------------------------------
+    //   ppix: pixel index in the image batch (0 with pmask 0 when outside the image / no piece)
+    //   pdst: LDS byte offset inside a halo buffer, or -1 -> the thread's dummy slot
+    int ppix[PIECE_ITERS], pdst[PIECE_ITERS]; unsigned pmask[PIECE_ITERS];
+#pragma unroll
+    for (int j = 0; j < PIECE_ITERS; ++j) {
+        const int idx = j * 512 + tid;
+        const int pix = idx / PARTS;
+        const int hy = pix / V2_HE, hx = pix - hy * V2_HE;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const bool inb = idx < NPIECE && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        ppix[j] = inb ? (b * p.H + gy) * p.W + gx : 0;
+        pmask[j] = inb ? 0xffffffffu : 0u;
+        pdst[j] = idx < NPIECE ? pix * ROWB + part * 16 : -1;
+    }
+    const int dummy_off = MAIN_BYTES + tid * 16;
+    float ca[VEC], cb[VEC];                                  // GroupNorm affine of the chunk being staged
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { ca[k] = 1.f; cb[k] = 0.f; }
+    auto load_coef = [&](int chunk) {
+        if (p.coef) {
+            const float* cf = p.coef + ((size_t)b * Ctot + chunk * CK + part * VEC) * 2;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { ca[k] = cf[2 * k]; cb[k] = cf[2 * k + 1]; }
+        }
+    };
+    auto src_ptr0 = [&](int chunk, int pixoff) -> const uint4* {
+        const int c_glob = chunk * CK;
+        const TIN* src; int Cs, c_loc;
+        if (c_glob < p.C0) { src = (const TIN*)p.src0; Cs = p.C0; c_loc = c_glob; }
+        else               { src = (const TIN*)p.src1; Cs = p.C1; c_loc = c_glob - p.C0; }
+        return reinterpret_cast<const uint4*>(src + (size_t)pixoff * Cs + c_loc + part * VEC);
+    };
+    // ---- segment-1 (shortcut) pieces: centre 16x16 pixels only, 4 per thread, raw ---------------------------------
+    auto load_piece1 = [&](int chunk2, int q, uint4& raw) -> unsigned {
+        const int pix = (q * 512 + tid) / PARTS;             // 0..255
+        const int gy = ty0 + (pix >> 4), gx = tx0 + (pix & 15);
+        const bool inb = gy < p.H && gx < p.W;
+        const int c_glob = chunk2 * CK;
+        const TIN* src; int Cs, c_loc;
+        if (c_glob < p.XC0) { src = (const TIN*)p.x0; Cs = p.XC0; c_loc = c_glob; }
+        else                { src = (const TIN*)p.x1; Cs = p.XC1; c_loc = c_glob - p.XC0; }
+        const size_t pixoff = inb ? (size_t)(b * p.H + gy) * p.W + gx : 0;
+        raw = *reinterpret_cast<const uint4*>(src + pixoff * Cs + c_loc + part * VEC);
+        return inb ? 0xffffffffu : 0u;
+    };
+    auto piece1_dst = [&](int q, int hb) -> int {
+        const int pix = (q * 512 + tid) / PARTS;
+        return hb * HALO_BYTES + (((pix >> 4) + 1) * V2_HE + (pix & 15) + 1) * ROWB + part * 16;
+    };
+
+    // ---- weights: 2 pieces per thread per (tap, chunk) slab; 32-bit element offsets from a uniform slab pointer -------
+    const int wrow0 = tid / PARTS, wrow1 = (tid + 512) / PARTS;
+    const unsigned wo0 = wrow0 * Ctot + part * VEC, wo1 = wrow1 * Ctot + part * VEC;          // segment 0 (ld = Ctot)
+    const int wdst0 = 2 * HALO_BYTES + wrow0 * ROWB + part * 16, wdst1 = 2 * HALO_BYTES + wrow1 * ROWB + part * 16;
+    const size_t tapstride = (size_t)p.cout_pad * Ctot;                                       // elements between taps
+    const TIN* const wseg0 = (const TIN*)p.w + (size_t)n0 * Ctot;
+    // weights of iteration (chunk CC, tap TT) -> R0/R1 ; TT may run past 8 (wraps into the next chunk)
+#define V2_LOAD_W(CC, TT, R0, R1)                                                                                    \
+    {                                                                                                                \
+        const int cw_ = (TT) > 8 ? (CC) + 1 : (CC);                                                                  \
+        const int tw_ = (TT) > 8 ? (TT)-9 : (TT);                                                                    \
+        if (cw_ < nchunks) {                                                                                         \
+            const TIN* wb_ = wseg0 + tw_ * tapstride + cw_ * CK;                                                     \
+            R0 = *reinterpret_cast<const uint4*>(wb_ + wo0); R1 = *reinterpret_cast<const uint4*>(wb_ + wo1);        \
+        }                                                                                                            \
+    }
+#define V2_STORE_W(BUF, R0, R1)                                                                     \
+    {                                                                                               \
+        *reinterpret_cast<uint4*>(smem + (BUF)*W_BYTES + wdst0) = R0;                               \
+        *reinterpret_cast<uint4*>(smem + (BUF)*W_BYTES + wdst1) = R1;                               \
+    }
+
+    // ---- prologue: chunk 0 halo (synchronous), weights of iteration 0 -------------------------------------------------
+    uint4 wa0 = make_uint4(0, 0, 0, 0), wa1 = wa0;
+    load_coef(0);
+#pragma unroll
+    for (int j = 0; j < PIECE_ITERS; ++j) {
+        const uint4 raw = *src_ptr0(0, ppix[j]);
+        *reinterpret_cast<uint4*>(smem + (pdst[j] >= 0 ? pdst[j] : dummy_off)) = v2_transform<TIN, ACT>(raw, pmask[j], ca, cb);
+    }
+    V2_LOAD_W(0, 0, wa0, wa1);
+    V2_STORE_W(0, wa0, wa1);
+
+    typename MF::frag af[KSTEPS][TM], bf[KSTEPS][TN];
+    uint4 hA = wa0, hB = wa0, t0 = wa0;                      // pieces in flight (even / odd tap) and the transformed piece
+    // Per (chunk CC, tap T) -- T is a literal, so every table index / LDS offset folds.  Piece k (0..5) of chunk CC+1:
+    //   global load issued in LDS(k) -> GroupNorm+SiLU on the VALU behind the MFMAs of MFMA(k+1) -> written in LDS(k+2).
+    // LDS phase: read the 16 fragments of (CC,T) first, then the LDS writes (transformed piece, next weight slab) and
+    // the global-load issue for later iterations, while the reads are in flight.
+#define V2_LDS(CC, T)                                                                                                \
+    {                                                                                                                \
+        const int cc_ = (CC);                                                                                        \
+        const int par_ = cc_ & 1;                            /* halo buffer this chunk reads; it parity = par_ ^ (T&1) */ \
+        const bool next_ = cc_ + 1 < nchunks;                                                                        \
+        {                                                                                                            \
+            const char* ha_ = smem + par_ * HALO_BYTES + (((T) / 3) * V2_HE + ((T) % 3)) * ROWB;                     \
+            const char* wbuf_ = smem + (par_ ^ ((T)&1)) * W_BYTES;                                                   \
+            _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk) {                                                  \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) af[kk][i] = MF::ld(ha_ + a_base[i] + kk * MF::KM * (int)sizeof(TIN)); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[kk][j] = MF::ld(wbuf_ + b_base[j] + kk * MF::KM * (int)sizeof(TIN)); \
+            }                                                                                                        \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if ((T) >= 2 && (T) < PIECE_ITERS + 2 && next_) {                                                            \
+            constexpr int k_ = (T) >= 2 && (T) < PIECE_ITERS + 2 ? (T)-2 : 0;                                        \
+            *reinterpret_cast<uint4*>(smem + (pdst[k_] >= 0 ? (par_ ^ 1) * HALO_BYTES + pdst[k_] : dummy_off)) = t0;  \
+        }                                                                                                            \
+        if ((T) < 8 || next_) V2_STORE_W((par_ ^ ((T)&1)) ^ 1, wa0, wa1);                                            \
+        if ((T) < PIECE_ITERS && next_) {                                                                            \
+            if ((T) == 0) load_coef(cc_ + 1);                                                                        \
+            constexpr int k_ = (T) < PIECE_ITERS ? (T) : 0;                                                          \
+            if ((T)&1) hB = *src_ptr0(cc_ + 1, ppix[k_]); else hA = *src_ptr0(cc_ + 1, ppix[k_]);                    \
+        }                                                                                                            \
+        V2_LOAD_W(cc_, (T) + 2, wa0, wa1);                                                                           \
+    }
+    // MFMA phase: 16 MFMAs on the fragments read in the preceding LDS phase; the piece loaded one iteration ago is
+    // normalised + activated on the VALU in their shadow.
+#define V2_MFMA(CC, T)                                                                                               \
+    {                                                                                                                \
+        _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk)                                                        \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                           \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);  \
+        if ((T) >= 1 && (T) < PIECE_ITERS + 1 && (CC) + 1 < nchunks) {                                               \
+            constexpr int k_ = (T) >= 1 && (T) < PIECE_ITERS + 1 ? (T)-1 : 0;                                        \
+            t0 = v2_transform<TIN, ACT>((k_ & 1) ? hB : hA, pmask[k_], ca, cb);                                      \
+        }                                                                                                            \
+    }
+
+    // Ping-pong schedule over the 3x3 segment: the two waves that share a SIMD (w and w+4) are always in opposite
+    // phases, one s_barrier per phase.
+    //   phase:   0        1        2        3        4       ...
+    //   G0:    LDS(0)  MFMA(0)  LDS(1)  MFMA(1)  LDS(2)
+    //   G1:     --     LDS(0)  MFMA(0)  LDS(1)  MFMA(1)
+    V2_LOAD_W(0, 1, wa0, wa1);                               // weights of iteration 1, stored by LDS(0)
+    // register-only MFMAs may legally move across s_barrier; pin the phases so the ping-pong survives scheduling
+#define V2_BAR() { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
+    V2_BAR();
+    if (wave < 4) {
+        V2_LDS(0, 0)
+        V2_BAR();
+        for (int c = 0; c < nchunks; ++c) {
+#define V2_G0_STEP(T) V2_MFMA(c, T) V2_BAR(); V2_LDS(c, (T) + 1) V2_BAR();
+            V2_G0_STEP(0) V2_G0_STEP(1) V2_G0_STEP(2) V2_G0_STEP(3) V2_G0_STEP(4) V2_G0_STEP(5) V2_G0_STEP(6) V2_G0_STEP(7)
+#undef V2_G0_STEP
+            V2_MFMA(c, 8)
+            V2_BAR();
+            if (c + 1 < nchunks) V2_LDS(c + 1, 0)
+            V2_BAR();
+        }
+    } else {
+        V2_BAR();
+        for (int c = 0; c < nchunks; ++c) {
+#define V2_G1_STEP(T) V2_LDS(c, T) V2_BAR(); V2_MFMA(c, T) V2_BAR();
+            V2_G1_STEP(0) V2_G1_STEP(1) V2_G1_STEP(2) V2_G1_STEP(3) V2_G1_STEP(4) V2_G1_STEP(5) V2_G1_STEP(6) V2_G1_STEP(7) V2_G1_STEP(8)
+#undef V2_G1_STEP
+        }
+    }
+#undef V2_BAR
+#undef V2_LDS
+#undef V2_LOAD_W
+
+    // ---- segment 1: the fused 1x1 shortcut (2-4 iterations): raw centre pixels, plain staged loop ---------------------
+    for (int c2 = 0; c2 < nchunks2; ++c2) {
+        uint4 r0, r1, r2, r3; unsigned m0, m1, m2, m3;
+        m0 = load_piece1(c2, 0, r0); m1 = load_piece1(c2, 1, r1); m2 = load_piece1(c2, 2, r2); m3 = load_piece1(c2, 3, r3);
+        const TIN* wb_ = (const TIN*)p.w2 + (size_t)n0 * XCtot + c2 * CK;
+        wa0 = *reinterpret_cast<const uint4*>(wb_ + wrow0 * XCtot + part * VEC);
+        wa1 = *reinterpret_cast<const uint4*>(wb_ + wrow1 * XCtot + part * VEC);
+        r0.x &= m0; r0.y &= m0; r0.z &= m0; r0.w &= m0; r1.x &= m1; r1.y &= m1; r1.z &= m1; r1.w &= m1;
+        r2.x &= m2; r2.y &= m2; r2.z &= m2; r2.w &= m2; r3.x &= m3; r3.y &= m3; r3.z &= m3; r3.w &= m3;
+        *reinterpret_cast<uint4*>(smem + piece1_dst(0, 0)) = r0; *reinterpret_cast<uint4*>(smem + piece1_dst(1, 0)) = r1;
+        *reinterpret_cast<uint4*>(smem + piece1_dst(2, 0)) = r2; *reinterpret_cast<uint4*>(smem + piece1_dst(3, 0)) = r3;
+        V2_STORE_W(0, wa0, wa1);
+        __syncthreads();
+        const char* ha_ = smem + (V2_HE + 1) * ROWB;          // centre tap of halo buffer 0
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[kk][i] = MF::ld(ha_ + a_base[i] + kk * MF::KM * (int)sizeof(TIN));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[kk][j] = MF::ld(smem + b_base[j] + kk * MF::KM * (int)sizeof(TIN));
+        }
+        V2_MFMA(nchunks, 0)
+        __syncthreads();
+    }
+#undef V2_MFMA
+#undef V2_STORE_W
+
+    // ------------------------------ epilogue (as conv_kernel: per-wave LDS transpose, 16-byte I/O) -------------------
+    constexpr int STG_LD = NW + 4;
+    constexpr int STG_WAVE = 32 * STG_LD * 4;
+    constexpr int CH = 16 / (int)sizeof(TOUT);
+    constexpr int CPR = NW / CH;
+    constexpr int QN = 32 * CPR / 64;
+    float* const stg = reinterpret_cast<float*>(smem + wave * STG_WAVE);
+    float* const red = reinterpret_cast<float*>(smem + 8 * STG_WAVE);     // [WM][BN][2]
+    TOUT* out = (TOUT*)p.out;
+    const TOUT* res = (const TOUT*)p.res;
+    float addv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn * NW + j * 32 + (lane & 31);
+        float add = 0.f;
+        if (co < p.Cout) {
+            if (p.bias) add += p.bias[co];
+            if (p.temb) add += p.temb[(size_t)b * p.temb_bstride + co];
+        }
+        addv[j] = add;
+    }
+    const int ch = lane % CPR;
+    const int co0 = n0 + wn * NW + ch * CH;
+    const bool cok = co0 < p.Cout;
+    float st_s[CH], st_q[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { st_s[c] = 0.f; st_q[c] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                stg[row * STG_LD + j * 32 + (lane & 31)] = acc[i][j][r] + addv[j];
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            const int row = (q * 64 + lane) / CPR;
+            const int m = wm * MW + i * 32 + row;
+            const int gy = ty0 + (m >> 4), gx = tx0 + (m & 15);
+            float v[CH];
+#pragma unroll
+            for (int c4 = 0; c4 < CH / 4; ++c4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(stg + row * STG_LD + ch * CH + c4 * 4);
+                v[c4 * 4] = t4.x; v[c4 * 4 + 1] = t4.y; v[c4 * 4 + 2] = t4.z; v[c4 * 4 + 3] = t4.w;
+            }
+            if (cok && gy < p.H && gx < p.W) {
+                const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+                if (res) {
+                    float rv[CH];
+                    Vec16<TOUT>::load(res + pix * p.Cout + co0, rv);
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) v[c] += rv[c];
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) v[c] *= p.out_scale;
+                if (p.pyr) {
+                    const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const float4 wq = *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4);
+                        v[c] += p.b4[co0 + c] + wq.x * pq.x + wq.y * pq.y + wq.z * pq.z + wq.w * pq.w;
+                    }
+                }
+                const uint4 packed = Vec16<TOUT>::pack(v);
+                *reinterpret_cast<uint4*>(out + pix * p.Cout + co0) = packed;
+                if (p.stats) {
+                    float vr[CH];
+                    Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&packed), vr);
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) { st_s[c] += vr[c]; st_q[c] += vr[c] * vr[c]; }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) { st_s[c] += __shfl_xor(st_s[c], o); st_q[c] += __shfl_xor(st_q[c], o); }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int cl = wn * NW + ch * CH + c;
+                red[(wm * BN + cl) * 2] = st_s[c]; red[(wm * BN + cl) * 2 + 1] = st_q[c];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+            const int co = n0 + tid;
+            if (co < p.Cout) {
+                float* dst = p.stats + (((size_t)b * gridDim.x + tile) * p.Cout + co) * 2;
+                dst[0] = s; dst[1] = q;
+            }
+        }
+    }
+}
+
+template <typename TIN, typename TOUT, int CK, bool ACT>
+static void v2_launch_t(const ConvArgs& a, hipStream_t s) {
+    constexpr int ROWB = CK * (int)sizeof(TIN) + 16;
+    constexpr int MAIN = 2 * V2_HALO * ROWB + 2 * V2_BN * ROWB + 512 * 16;
+    constexpr int EPI = 8 * 32 * (64 + 4) * 4 + 4 * V2_BN * 2 * 4;
+    constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
+    static bool attr_set = false;
+    auto kern = conv_v2_kernel<TIN, TOUT, CK, ACT>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr_set = true;
+    }
+    dim3 grid(conv_v2_tiles(a.H, a.W), (a.Cout + V2_BN - 1) / V2_BN, a.B);
+    hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, s, a);
+}
+
+bool conv_v2_eligible(const ConvArgs& a) {
+    const int Ctot = a.C0 + a.C1, XC = a.XC0 + a.XC1;
+    const int ck = a.in_dtype == DT_BF16 ? 64 : 32;
+    return a.ntaps == 9 && a.Cout > 32 && a.in_dtype == a.out_dtype && Ctot % ck == 0 && XC % ck == 0 && a.H >= V2_T &&
+           a.W >= V2_T;
+}
+
+void launch_conv_v2(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    static const int dbg = getenv("USE_HIP_DBG") ? atoi(getenv("USE_HIP_DBG")) : 0;
+    a.dbg = dbg;
+    if (a.in_dtype == DT_BF16) { a.act ? v2_launch_t<__bf16, __bf16, 64, true>(a, s) : v2_launch_t<__bf16, __bf16, 64, false>(a, s); }
+    else                       { a.act ? v2_launch_t<float, float, 32, true>(a, s) : v2_launch_t<float, float, 32, false>(a, s); }
+}
+
+}  // namespace use

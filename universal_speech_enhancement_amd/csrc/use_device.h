@@ -1,0 +1,74 @@
+// Device-side helpers shared by the gfx950 kernels (16-byte vector <-> float conversion, SiLU, MFMA traits).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace use {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define DEVI __device__ __forceinline__
+
+template <bool ACCURATE>
+DEVI float silu_f(float x) {
+    if (ACCURATE) return x / (1.0f + expf(-x));
+    return x * __frcp_rn(1.0f + __expf(-x));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 16-byte vector <-> float helpers
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    DEVI static void load(const float* p, float (&v)[4]) {
+        float4 u = *reinterpret_cast<const float4*>(p);
+        v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+    }
+    DEVI static uint4 pack(const float (&v)[4]) {
+        float4 u = make_float4(v[0], v[1], v[2], v[3]);
+        return __builtin_bit_cast(uint4, u);
+    }
+    DEVI static void store(float* p, const float (&v)[4]) { *reinterpret_cast<uint4*>(p) = pack(v); }
+};
+template <> struct Vec16<__bf16> {
+    static constexpr int N = 8;
+    DEVI static void load(const __bf16* p, float (&v)[8]) {
+        uint4 u = *reinterpret_cast<const uint4*>(p);
+        bf16x8 b = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)b[i];
+    }
+    DEVI static uint4 pack(const float (&v)[8]) {
+        bf16x8 b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = (__bf16)v[i];
+        return __builtin_bit_cast(uint4, b);
+    }
+    DEVI static void store(__bf16* p, const float (&v)[8]) { *reinterpret_cast<uint4*>(p) = pack(v); }
+};
+
+template <typename T> DEVI float to_f(T v) { return (float)v; }
+template <typename T> DEVI T from_f(float v) { return (T)v; }
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA traits: one 32x32 output tile per instruction; lanes 0-31 carry the first half of the K slab and lanes
+// 32-63 the second half, KPL contiguous k per lane (cdna_hip_programming.md section 3).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> struct Mfma;
+template <> struct Mfma<__bf16> {
+    static constexpr int KM = 16, KPL = 8;
+    typedef bf16x8 frag;
+    DEVI static frag ld(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+    DEVI static f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma<float> {
+    static constexpr int KM = 2, KPL = 1;
+    typedef float frag;
+    DEVI static frag ld(const char* p) { return *reinterpret_cast<const float*>(p); }
+    DEVI static f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+};
+
+}  // namespace use

@@ -56,7 +56,7 @@ struct PyrW { GNW gn; ConvW conv; };
 
 struct Expected { std::string name; std::vector<int64_t> shape; };
 
-struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, dtype = DT_F32; float* stats = nullptr; };
+struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, dtype = DT_F32; float* stats = nullptr; int ntiles = 0; };
 
 struct Arena {
     char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
@@ -324,7 +324,7 @@ struct Fwd {
         const int C = a.C + (a2 ? a2->C : 0);
         float* coef = (float*)h->arena.alloc((size_t)h->B * C * 2 * 4);
         if (!h->dry)
-            launch_gn_finalize(a.stats, a.C, a2 ? a2->stats : nullptr, a2 ? a2->C : 0, tiles_per_image(a.H, a.W),
+            launch_gn_finalize(a.stats, a.C, a.ntiles, a2 ? a2->stats : nullptr, a2 ? a2->C : 0, a2 ? a2->ntiles : 0,
                                W<float>(g.g_off), W<float>(g.b_off), std::min(C / 4, 32), a.H * a.W, 1e-6f, coef,
                                h->B, s);
         return coef;
@@ -348,6 +348,7 @@ struct Fwd {
         p.pyr = pyr; p.w4 = cb ? W<float>(cb->w_off) : nullptr; p.b4 = cb ? W<float>(cb->b_off) : nullptr;
         p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
         p.B = h->B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
+        o.ntiles = conv_out_tiles(p);
         const bool main_variant = a.dtype == h->act_dtype && out_dtype == h->act_dtype && w.cout > 32;
         if (h->profile && main_variant) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);

@@ -13,6 +13,7 @@ constexpr int TILE_H = 8;    // conv output tile: 8 x 16 pixels = 128 GEMM rows
 constexpr int TILE_W = 16;
 
 inline int tiles_per_image(int H, int W) { return ((H + TILE_H - 1) / TILE_H) * ((W + TILE_W - 1) / TILE_W); }
+inline int conv_v2_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 15) / 16); }   // conv_v2_kernel: 16x16 tiles
 
 // Implicit-GEMM convolution (3x3 pad 1, or 1x1) with fused prologue / epilogue.
 //   in   = concat(src0[C0], src1[C1]) along channels, optional per-(b, channel) affine
@@ -39,12 +40,18 @@ struct ConvArgs {
     void* out; int out_dtype;
     float* stats;           // or null
     int B, H, W, Cout, ntaps;
+    int dbg;                // ablation bits for kernel bring-up (0 in production)
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
+// software-pipelined variant for large maps (use_conv_v2.hip); launch_conv dispatches to it when eligible
+bool conv_v2_eligible(const ConvArgs& a);
+void launch_conv_v2(const ConvArgs& a, hipStream_t s);
+// number of per-image statistics tiles the kernel chosen for `a` writes (stats layout [B][tiles][Cout][2])
+inline int conv_out_tiles(const ConvArgs& a) { return conv_v2_eligible(a) ? conv_v2_tiles(a.H, a.W) : tiles_per_image(a.H, a.W); }
 
 // GroupNorm finalisation: per-(b, group) mean / rstd from per-tile per-channel partial sums of up to
 // two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b):  y = a*x + b.
-void launch_gn_finalize(const float* st0, int C0, const float* st1, int C1, int ntiles, const float* gamma,
+void launch_gn_finalize(const float* st0, int C0, int ntiles0, const float* st1, int C1, int ntiles1, const float* gamma,
                         const float* beta, int groups, int hw, float eps, float* coef, int B, hipStream_t s);
 
 // FIR x2 resampling with the separable [1,3,3,1] kernel (upfirdn2d semantics of the reference).

@@ -19,76 +19,11 @@
 // is staged in LDS once per channel chunk and re-used by the 9 taps; weights stream through a double-buffered
 // LDS slab.  Wave = 64 lanes everywhere.
 #include "use_kernels.h"
+#include "use_device.h"
 
 #include <math.h>
 
 namespace use {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-#define DEVI __device__ __forceinline__
-
-template <bool ACCURATE>
-DEVI float silu_f(float x) {
-    if (ACCURATE) return x / (1.0f + expf(-x));
-    return x * __frcp_rn(1.0f + __expf(-x));
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// 16-byte vector <-> float helpers
-// ---------------------------------------------------------------------------------------------------------
-template <typename T> struct Vec16;
-template <> struct Vec16<float> {
-    static constexpr int N = 4;
-    DEVI static void load(const float* p, float (&v)[4]) {
-        float4 u = *reinterpret_cast<const float4*>(p);
-        v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
-    }
-    DEVI static uint4 pack(const float (&v)[4]) {
-        float4 u = make_float4(v[0], v[1], v[2], v[3]);
-        return __builtin_bit_cast(uint4, u);
-    }
-    DEVI static void store(float* p, const float (&v)[4]) { *reinterpret_cast<uint4*>(p) = pack(v); }
-};
-template <> struct Vec16<__bf16> {
-    static constexpr int N = 8;
-    DEVI static void load(const __bf16* p, float (&v)[8]) {
-        uint4 u = *reinterpret_cast<const uint4*>(p);
-        bf16x8 b = __builtin_bit_cast(bf16x8, u);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (float)b[i];
-    }
-    DEVI static uint4 pack(const float (&v)[8]) {
-        bf16x8 b;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) b[i] = (__bf16)v[i];
-        return __builtin_bit_cast(uint4, b);
-    }
-    DEVI static void store(__bf16* p, const float (&v)[8]) { *reinterpret_cast<uint4*>(p) = pack(v); }
-};
-
-template <typename T> DEVI float to_f(T v) { return (float)v; }
-template <typename T> DEVI T from_f(float v) { return (T)v; }
-
-// ---------------------------------------------------------------------------------------------------------
-// MFMA traits: one 32x32 output tile per instruction; lanes 0-31 carry the first half of the K slab and lanes
-// 32-63 the second half, KPL contiguous k per lane (cdna_hip_programming.md section 3).
-// ---------------------------------------------------------------------------------------------------------
-template <typename T> struct Mfma;
-template <> struct Mfma<__bf16> {
-    static constexpr int KM = 16, KPL = 8;
-    typedef bf16x8 frag;
-    DEVI static frag ld(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
-    DEVI static f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct Mfma<float> {
-    static constexpr int KM = 2, KPL = 1;
-    typedef float frag;
-    DEVI static frag ld(const char* p) { return *reinterpret_cast<const float*>(p); }
-    DEVI static f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-};
 
 // ---------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution
@@ -373,6 +308,7 @@ static void conv_launch_t(const ConvArgs& a, hipStream_t s) {
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {
+    if (conv_v2_eligible(a)) { launch_conv_v2(a, s); return; }
     const int Ctot = a.C0 + a.C1;
     const bool small_n = a.Cout <= 32;
     if (a.in_dtype == DT_BF16) {
@@ -393,18 +329,20 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------
 // GroupNorm finalize: one block per (group, batch item)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ st0, int C0,
-                                                          const float* __restrict__ st1, int C1, int ntiles,
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ st0, int C0, int nt0,
+                                                          const float* __restrict__ st1, int C1, int nt1,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int groups, int hw,
                                                           float eps, float* __restrict__ coef) {
     const int g = blockIdx.x, b = blockIdx.y;
     const int C = C0 + C1, cpg = C / groups;
     double s = 0.0, q = 0.0;
-    for (int idx = threadIdx.x; idx < ntiles * cpg; idx += 256) {
+    const int ntmax = nt0 > nt1 ? nt0 : nt1;                 // the two sources may come from kernels with different tilings
+    for (int idx = threadIdx.x; idx < ntmax * cpg; idx += 256) {
         const int tile = idx / cpg, c = g * cpg + (idx - tile * cpg);
-        const float* p = (c < C0) ? st0 + (((size_t)b * ntiles + tile) * C0 + c) * 2
-                                  : st1 + (((size_t)b * ntiles + tile) * C1 + (c - C0)) * 2;
+        const float* p;
+        if (c < C0) { if (tile >= nt0) continue; p = st0 + (((size_t)b * nt0 + tile) * C0 + c) * 2; }
+        else        { if (tile >= nt1) continue; p = st1 + (((size_t)b * nt1 + tile) * C1 + (c - C0)) * 2; }
         s += (double)p[0]; q += (double)p[1];
     }
     __shared__ double rs[4], rq[4];
@@ -426,9 +364,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
-void launch_gn_finalize(const float* st0, int C0, const float* st1, int C1, int ntiles, const float* gamma,
+void launch_gn_finalize(const float* st0, int C0, int ntiles0, const float* st1, int C1, int ntiles1, const float* gamma,
                         const float* beta, int groups, int hw, float eps, float* coef, int B, hipStream_t s) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, st0, C0, st1, C1, ntiles, gamma, beta,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, st0, C0, ntiles0, st1, C1, ntiles1, gamma, beta,
                        groups, hw, eps, coef);
 }
 
