@@ -48,9 +48,9 @@ def usable_cores():
 
 
 def cpu_baseline(sd_np):
-    """CPU oracle on a bounded sample: 1 utterance of 64 frames, one score evaluation per thread-count candidate
-    (the best is kept: torch's CPU conv does not scale to hundreds of threads on this shape), then N=1 PC step with
-    Langevin x1 (2 NFE) at the best thread count."""
+    """CPU oracle on a bounded sample: one 64-frame score evaluation per thread-count candidate (the best is kept: torch's
+    CPU conv does not scale to hundreds of threads on this shape), then a PC sampler with Langevin x1 on 2 utterances of
+    128 frames at the best thread count, N chosen so the sample takes roughly 10-30 s."""
     from oracle import ncsnpp_oracle as no
     from oracle import sde_oracle as so
     from universal_speech_enhancement_amd.testing import noise as tn
@@ -71,16 +71,21 @@ def cpu_baseline(sd_np):
             if d > 20.0:
                 break
         torch.set_num_threads(best)
-        draws = [torch.from_numpy(d) for d in tn.sampler_noise(1, 3, (1, 1, 512, 64))]
+        est_rate = 64.0 / best_dt                                   # frame*NFE/s from the probe
+        n_utt, fr = 2, 128
+        N = int(max(1, min(15, round(est_rate * 15.0 / (n_utt * fr * 2)))))   # aim at ~15 s of CPU work
+        L = (fr - 1) * 160
+        wav = torch.from_numpy(tn.synth_noisy_speech(n_utt, L, seed=4242))
+        draws = [torch.from_numpy(d) for d in tn.sampler_noise(1, 1 + 2 * N, (n_utt, 1, 512, fr))]
         t0 = time.time()
-        _, _, Y, nfe = so.score_model_sample(lambda xx, t: no.ncsnpp_forward(sd, xx, t), wav, N=1, corrector="langevin",
+        _, _, Y, nfe = so.score_model_sample(lambda xx, t: no.ncsnpp_forward(sd, xx, t), wav, N=N, corrector="langevin",
                                              corrector_steps=1, snr=0.5, noise=so.NoiseSource(replay=draws))
         dt = time.time() - t0
-    frames = 1 + L // 160
+    frames = n_utt * (1 + L // 160)
     frame_nfe_per_s = frames * nfe / dt
     return {"value": round(frame_nfe_per_s / 60.0, 4), "unit": "spectrogram-frames/s", "cores": best, "kind": "port",
-            "sample": f"CPU oracle (torch fp32, {best} of {avail} usable cores): 1 utterance x {frames} frames, N=1 PC step = "
-                      f"{nfe} NFE in {dt:.1f} s ({frame_nfe_per_s:.1f} frame*NFE/s), scaled linearly to 60 NFE"}
+            "sample": f"CPU oracle (torch fp32, {best} of {avail} usable cores): {n_utt} utterances x {fr} frames, {N}-step PC "
+                      f"sampler = {nfe} NFE in {dt:.1f} s ({frame_nfe_per_s:.1f} frame*NFE/s), scaled linearly to 60 NFE"}
 
 
 def main():
@@ -157,7 +162,7 @@ def main():
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None,
-                "kernel": "use::conv_kernel<%s> (implicit-GEMM 3x3/1x1, BN=128)" % ("bf16,bf16,CK=64" if a.precision == "bf16" else "f32,f32,CK=32"),
+                "kernel": "use::conv_v2_kernel<%s> (implicit-GEMM 3x3 conv, both ACT variants)" % ("bf16,bf16,64" if a.precision == "bf16" else "f32,f32,32"),
                 "launches_per_score": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                 "algorithmic_gflop_per_launch": round(conv_flops / max(conv_launches, 1) / 1e9, 2),
                 "kernel_time_share_of_score": round(conv_ms / total_ms, 3),

@@ -248,3 +248,21 @@ def test_predict_step_writes_trimmed_wavs(tmp_path, sd_np):
     sr, a = wavfile.read(f"{dst}/x/a.wav"); _, b = wavfile.read(f"{dst}/b.wav")
     assert sr == 24000 and a.shape == (8000,) and b.shape == (5000,) and a.dtype == np.float32
     np.testing.assert_allclose(b, out["enhanced"][1, :5000].cpu().numpy(), atol=1e-6)
+
+
+def test_weight_blob_broadcast_equivalence(engines, sd_np):
+    """Stand-in for the RCCL weight broadcast on one GPU: a second handle that only *receives* rank 0's packed blob
+    (alloc_weight_blob + device copy into the aliased view) must reproduce rank 0's outputs bit for bit."""
+    from universal_speech_enhancement_amd.hip_engine import HipScoreEngine
+    src = engines["bf16"]
+    dst = HipScoreEngine(precision="bf16")
+    dst.alloc_weight_blob()
+    a, b = src.weight_blob(), dst.weight_blob()
+    assert a.dtype == torch.uint8 and a.shape == b.shape and a.data_ptr() != b.data_ptr()
+    b.copy_(a)                                   # what dist.broadcast does on the non-root ranks
+    assert dst.weight_blob().data_ptr() == b.data_ptr(), "the view must alias the library's blob, not a copy"
+    x = torch.from_numpy(tnoise.complex_normal(3, "bx", (1, 1, 512, 64))).cuda()
+    y = torch.from_numpy(tnoise.complex_normal(3, "by", (1, 1, 512, 64))).cuda()
+    t = torch.tensor([0.4], device="cuda")
+    assert torch.equal(src.score(x, y, t), dst.score(x, y, t))
+    dst.close()

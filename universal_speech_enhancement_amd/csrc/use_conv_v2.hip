@@ -166,15 +166,20 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
     }
 
     // ---- prologue: chunk 0 halo (synchronous), weights of iteration 0 -------------------------------------------------
+    // all global loads of the prologue are issued together (one exposed memory latency, not three)
     uint4 wa0 = make_uint4(0, 0, 0, 0), wa1 = wa0;
-    load_coef(0);
+    {
+        uint4 w00 = wa0, w01 = wa0, raw[PIECE_ITERS];
+        V2_LOAD_W(0, 0, w00, w01);
+        V2_LOAD_W(0, 1, wa0, wa1);                           // weights of iteration 1, stored by LDS(0)
 #pragma unroll
-    for (int j = 0; j < PIECE_ITERS; ++j) {
-        const uint4 raw = *src_ptr0(0, ppix[j]);
-        *reinterpret_cast<uint4*>(smem + (pdst[j] >= 0 ? pdst[j] : dummy_off)) = v2_transform<TIN, ACT>(raw, pmask[j], ca, cb);
+        for (int j = 0; j < PIECE_ITERS; ++j) raw[j] = *src_ptr0(0, ppix[j]);
+        load_coef(0);
+        V2_STORE_W(0, w00, w01);
+#pragma unroll
+        for (int j = 0; j < PIECE_ITERS; ++j)
+            *reinterpret_cast<uint4*>(smem + (pdst[j] >= 0 ? pdst[j] : dummy_off)) = v2_transform<TIN, ACT>(raw[j], pmask[j], ca, cb);
     }
-    V2_LOAD_W(0, 0, wa0, wa1);
-    V2_STORE_W(0, wa0, wa1);
 
     typename MF::frag af[KSTEPS][TM], bf[KSTEPS][TN];
     uint4 hA = wa0, hB = wa0, t0 = wa0;                      // pieces in flight (even / odd tap) and the transformed piece
@@ -215,9 +220,15 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
         _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk)                                                        \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                           \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);  \
-        if ((T) >= 1 && (T) < PIECE_ITERS + 1 && (CC) + 1 < nchunks) {                                               \
+        if ((T) >= 1 && (T) < PIECE_ITERS + 1) {             /* unconditional at run time: same basic block as the MFMAs */ \
             constexpr int k_ = (T) >= 1 && (T) < PIECE_ITERS + 1 ? (T)-1 : 0;                                        \
             t0 = v2_transform<TIN, ACT>((k_ & 1) ? hB : hA, pmask[k_], ca, cb);                                      \
+            asm volatile("" : "+v"(t0.x), "+v"(t0.y), "+v"(t0.z), "+v"(t0.w));   /* materialise here, not at the ds_write */ \
+            _Pragma("unroll") for (int g = 0; g < TM * TN * KSTEPS; ++g) {                                           \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA  */                                   \
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   /* 3 VALU  */                                   \
+                __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);   /* 1 TRANS */                                   \
+            }                                                                                                        \
         }                                                                                                            \
     }
 
@@ -226,7 +237,6 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
     //   phase:   0        1        2        3        4       ...
     //   G0:    LDS(0)  MFMA(0)  LDS(1)  MFMA(1)  LDS(2)
     //   G1:     --     LDS(0)  MFMA(0)  LDS(1)  MFMA(1)
-    V2_LOAD_W(0, 1, wa0, wa1);                               // weights of iteration 1, stored by LDS(0)
     // register-only MFMAs may legally move across s_barrier; pin the phases so the ping-pong survives scheduling
 #define V2_BAR() { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
     V2_BAR();
@@ -308,6 +318,21 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
     float st_s[CH], st_q[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) { st_s[c] = 0.f; st_q[c] = 0.f; }
+    // residual pieces of both staging rounds are fetched up front (their HBM latency overlaps the LDS transposes)
+    uint4 resv[TM][QN];
+    if (res) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                const int row = (q * 64 + lane) / CPR;
+                const int m = wm * MW + i * 32 + row;
+                const int gy = ty0 + (m >> 4), gx = tx0 + (m & 15);
+                const bool ok = cok && gy < p.H && gx < p.W;
+                const size_t pix = ok ? (size_t)(b * p.H + gy) * p.W + gx : 0;
+                resv[i][q] = *reinterpret_cast<const uint4*>(res + pix * p.Cout + (ok ? co0 : 0));
+            }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -333,7 +358,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
                 const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
                 if (res) {
                     float rv[CH];
-                    Vec16<TOUT>::load(res + pix * p.Cout + co0, rv);
+                    Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&resv[i][q]), rv);
 #pragma unroll
                     for (int c = 0; c < CH; ++c) v[c] += rv[c];
                 }

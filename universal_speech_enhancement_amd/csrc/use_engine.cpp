@@ -349,7 +349,7 @@ struct Fwd {
         p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
         p.B = h->B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
         o.ntiles = conv_out_tiles(p);
-        const bool main_variant = a.dtype == h->act_dtype && out_dtype == h->act_dtype && w.cout > 32;
+        const bool main_variant = conv_v2_eligible(p);        // the dominant kernel: conv_v2_kernel launches only
         if (h->profile && main_variant) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, s);
