@@ -147,3 +147,29 @@ def test_ouve_sde_host_math_matches_oracle():
     sde.N = 30
     f, G = sde.discretize(x, t, y)
     assert torch.allclose(G, g1 * (1 / 30) ** 0.5)
+
+
+def test_predict_config_composition_and_loader(tmp_path):
+    """Hydra-shaped overrides compose like the reference's CLI; the loader reproduces the collate dict."""
+    from scipy.io import wavfile
+    from universal_speech_enhancement_amd import predict as P
+    cfg = P.compose(["model=SGMSE_Large", "ckpt_path=foo.ckpt", "data.data_folder=/in", "model.Score.precision=fp32",
+                     "model.sampler_kwargs.N=30", "data.batch_size=2"])
+    assert cfg["ckpt_path"] == "foo.ckpt" and cfg["data"]["data_folder"] == "/in" and cfg["data"]["batch_size"] == 2
+    assert cfg["model"]["Score"]["precision"] == "fp32" and cfg["model"]["sampler_kwargs"] == {"N": 30}
+    assert cfg["model"]["Score"]["n_fft"] == 1022 and cfg["model"]["Score"]["t_eps"] == 3e-2
+    src = tmp_path / "in" / "sub"
+    src.mkdir(parents=True)
+    rng = np.random.RandomState(0)
+    wavfile.write(str(src / "a.wav"), 24000, (rng.randn(3000) * 0.1).astype(np.float32))
+    wavfile.write(str(tmp_path / "in" / "b.wav"), 48000, (rng.randn(8000, 2) * 3000).astype(np.int16))
+    data = P.instantiate({**cfg["data"], "data_folder": str(tmp_path / "in"), "target_folder": str(tmp_path / "out")})
+    batches = list(data.predict_batches(device="cpu"))
+    assert len(batches) == 1
+    b = batches[0]
+    assert set(b) == {"perturbed", "name", "sample_length", "sampling_rate", "audio_path", "data_folder", "target_folder"}
+    assert sorted(b["name"]) == ["a", "b"] and b["sampling_rate"] == [24000, 24000]
+    assert b["perturbed"].shape == (2, 4000) and sorted(b["sample_length"].tolist()) == [3000, 4000]
+    assert abs(float(b["perturbed"].abs().max()) - 0.8) < 1e-6
+    model = P.instantiate(cfg["model"])
+    assert type(model).__name__ == "SGMSEModule" and model.sampler_kwargs == {"N": 30} and model.Score.precision == "fp32"
