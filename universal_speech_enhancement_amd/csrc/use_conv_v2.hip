@@ -14,6 +14,7 @@
 #include "use_kernels.h"
 #include "use_device.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace use {
@@ -51,7 +52,10 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
     constexpr int ROWB = CK * (int)sizeof(TIN) + 16;
     constexpr int BN = V2_BN, WM = 4, WN = 2, MW = 64, NW = 64, TM = 2, TN = 2;
     constexpr int KSTEPS = CK / MF::KM;
-    constexpr int HALO_BYTES = V2_HALO * ROWB, W_BYTES = BN * ROWB;
+    // halo row pitch padded to a multiple of 256 B: the two pixel rows a 32-row MFMA fragment read touches then fall on
+    // disjoint LDS bank slots (ds_read_b128 lane groups mix lanes of both rows) -- removes the A-operand bank conflicts
+    constexpr int HPITCH = (V2_HE * ROWB / 16 + 15) / 16 * 16 * 16;
+    constexpr int HALO_BYTES = V2_HE * HPITCH, W_BYTES = BN * ROWB;
     constexpr int MAIN_BYTES = 2 * HALO_BYTES + 2 * W_BYTES;
     constexpr int NPIECE = V2_HALO * PARTS;                 // 16-byte pieces per halo chunk (2592)
     constexpr int PIECE_ITERS = (NPIECE + 511) / 512;       // taps that carry one piece per thread (6)
@@ -74,6 +78,39 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
     const int nchunks2 = XCtot / CK;
     const int part = tid & (PARTS - 1);
 
+    // per-lane epilogue constants (bias + time-embedding bias of this lane's output channels): fetched first so their
+    // latency is hidden behind the whole main loop instead of being exposed at the start of the epilogue
+    float addv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = n0 + wn * 64 + j * 32 + (lane & 31);
+        float add = 0.f;
+        if (co < p.Cout) {
+            if (p.bias) add += p.bias[co];
+            if (p.temb) add += p.temb[(size_t)b * p.temb_bstride + co];
+        }
+        addv[j] = add;
+    }
+
+    // optional timeline: lane 0 of waves 0 and 4 of workgroup (0,0,0) stamp s_memtime at phase boundaries
+    const bool tracing = p.trace != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave & 3) == 0;
+    int trace_n = 0;
+#ifdef USE_HIP_TRACE_BUILD   /* make CXXFLAGS+=-DUSE_HIP_TRACE_BUILD: the stamps' stores perturb the waitcnt placement */
+#define V2_STAMP(ID)                                                                                   \
+    if (tracing && trace_n < 120) {                                                                    \
+        p.trace[(wave >> 2) * 256 + 2 * trace_n] = (unsigned long long)(ID);                           \
+        p.trace[(wave >> 2) * 256 + 2 * trace_n + 1] = __builtin_readcyclecounter(); ++trace_n;        \
+    }
+#else
+#define V2_STAMP(ID)
+    (void)tracing; (void)trace_n;
+#endif
+#ifdef USE_HIP_TRACE_FINE
+#define V2_STAMPF(ID) V2_STAMP(ID)
+#else
+#define V2_STAMPF(ID)
+#endif
+    V2_STAMP(1)
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -86,7 +123,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = wm * MW + i * 32 + (lane & 31);
-        a_base[i] = ((m >> 4) * V2_HE + (m & 15)) * ROWB + (lane >> 5) * MF::KPL * (int)sizeof(TIN);
+        a_base[i] = (m >> 4) * HPITCH + (m & 15) * ROWB + (lane >> 5) * MF::KPL * (int)sizeof(TIN);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -105,7 +142,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
         const bool inb = idx < NPIECE && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         ppix[j] = inb ? (b * p.H + gy) * p.W + gx : 0;
         pmask[j] = inb ? 0xffffffffu : 0u;
-        pdst[j] = idx < NPIECE ? pix * ROWB + part * 16 : -1;
+        pdst[j] = idx < NPIECE ? hy * HPITCH + hx * ROWB + part * 16 : -1;
     }
     const int dummy_off = MAIN_BYTES + tid * 16;
     float ca[VEC], cb[VEC];                                  // GroupNorm affine of the chunk being staged
@@ -140,7 +177,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
     };
     auto piece1_dst = [&](int q, int hb) -> int {
         const int pix = (q * 512 + tid) / PARTS;
-        return hb * HALO_BYTES + (((pix >> 4) + 1) * V2_HE + (pix & 15) + 1) * ROWB + part * 16;
+        return hb * HALO_BYTES + ((pix >> 4) + 1) * HPITCH + ((pix & 15) + 1) * ROWB + part * 16;
     };
 
     // ---- weights: 2 pieces per thread per (tap, chunk) slab; 32-bit element offsets from a uniform slab pointer -------
@@ -181,8 +218,9 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
             *reinterpret_cast<uint4*>(smem + (pdst[j] >= 0 ? pdst[j] : dummy_off)) = v2_transform<TIN, ACT>(raw[j], pmask[j], ca, cb);
     }
 
+    V2_STAMP(2)
     typename MF::frag af[KSTEPS][TM], bf[KSTEPS][TN];
-    uint4 hA = wa0, hB = wa0, t0 = wa0;                      // pieces in flight (even / odd tap) and the transformed piece
+    uint4 hL = wa0, hT = wa0, t0 = wa0;                      // piece in flight, piece being transformed, transformed piece
     // Per (chunk CC, tap T) -- T is a literal, so every table index / LDS offset folds.  Piece k (0..5) of chunk CC+1:
     //   global load issued in LDS(k) -> GroupNorm+SiLU on the VALU behind the MFMAs of MFMA(k+1) -> written in LDS(k+2).
     // LDS phase: read the 16 fragments of (CC,T) first, then the LDS writes (transformed piece, next weight slab) and
@@ -192,8 +230,9 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
         const int cc_ = (CC);                                                                                        \
         const int par_ = cc_ & 1;                            /* halo buffer this chunk reads; it parity = par_ ^ (T&1) */ \
         const bool next_ = cc_ + 1 < nchunks;                                                                        \
+        V2_STAMPF(100 + (T))                                                                                          \
         {                                                                                                            \
-            const char* ha_ = smem + par_ * HALO_BYTES + (((T) / 3) * V2_HE + ((T) % 3)) * ROWB;                     \
+            const char* ha_ = smem + par_ * HALO_BYTES + ((T) / 3) * HPITCH + ((T) % 3) * ROWB;                      \
             const char* wbuf_ = smem + (par_ ^ ((T)&1)) * W_BYTES;                                                   \
             _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk) {                                                  \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i) af[kk][i] = MF::ld(ha_ + a_base[i] + kk * MF::KM * (int)sizeof(TIN)); \
@@ -201,28 +240,38 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
             }                                                                                                        \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
+        V2_STAMPF(500 + (T))                                                                                          \
         if ((T) >= 2 && (T) < PIECE_ITERS + 2 && next_) {                                                            \
             constexpr int k_ = (T) >= 2 && (T) < PIECE_ITERS + 2 ? (T)-2 : 0;                                        \
             *reinterpret_cast<uint4*>(smem + (pdst[k_] >= 0 ? (par_ ^ 1) * HALO_BYTES + pdst[k_] : dummy_off)) = t0;  \
         }                                                                                                            \
         if ((T) < 8 || next_) V2_STORE_W((par_ ^ ((T)&1)) ^ 1, wa0, wa1);                                            \
+        V2_STAMPF(600 + (T))                                                                                          \
+        if ((T) >= 1 && (T) < PIECE_ITERS + 1) {                                                                     \
+            /* the piece loaded one iteration ago has landed (older than the weights just waited for): park it in  */ \
+            /* plain registers so the MFMA-phase transform carries no vmcnt wait on this phase's fresh loads       */ \
+            hT = hL;                                                                                                 \
+            asm volatile("" : "+v"(hT.x), "+v"(hT.y), "+v"(hT.z), "+v"(hT.w));                                       \
+        }                                                                                                            \
         if ((T) < PIECE_ITERS && next_) {                                                                            \
             if ((T) == 0) load_coef(cc_ + 1);                                                                        \
             constexpr int k_ = (T) < PIECE_ITERS ? (T) : 0;                                                          \
-            if ((T)&1) hB = *src_ptr0(cc_ + 1, ppix[k_]); else hA = *src_ptr0(cc_ + 1, ppix[k_]);                    \
+            hL = *src_ptr0(cc_ + 1, ppix[k_]);                                                                       \
         }                                                                                                            \
         V2_LOAD_W(cc_, (T) + 2, wa0, wa1);                                                                           \
+        V2_STAMPF(200 + (T))                                                                                          \
     }
     // MFMA phase: 16 MFMAs on the fragments read in the preceding LDS phase; the piece loaded one iteration ago is
     // normalised + activated on the VALU in their shadow.
 #define V2_MFMA(CC, T)                                                                                               \
     {                                                                                                                \
+        V2_STAMPF(300 + (T))                                                                                          \
         _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk)                                                        \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                           \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);  \
         if ((T) >= 1 && (T) < PIECE_ITERS + 1) {             /* unconditional at run time: same basic block as the MFMAs */ \
             constexpr int k_ = (T) >= 1 && (T) < PIECE_ITERS + 1 ? (T)-1 : 0;                                        \
-            t0 = v2_transform<TIN, ACT>((k_ & 1) ? hB : hA, pmask[k_], ca, cb);                                      \
+            t0 = v2_transform<TIN, ACT>(hT, pmask[k_], ca, cb);                                                      \
             asm volatile("" : "+v"(t0.x), "+v"(t0.y), "+v"(t0.z), "+v"(t0.w));   /* materialise here, not at the ds_write */ \
             _Pragma("unroll") for (int g = 0; g < TM * TN * KSTEPS; ++g) {                                           \
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* 1 MFMA  */                                   \
@@ -230,6 +279,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
                 __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);   /* 1 TRANS */                                   \
             }                                                                                                        \
         }                                                                                                            \
+        V2_STAMPF(400 + (T))                                                                                          \
     }
 
     // Ping-pong schedule over the 3x3 segment: the two waves that share a SIMD (w and w+4) are always in opposite
@@ -264,6 +314,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
 #undef V2_LDS
 #undef V2_LOAD_W
 
+    V2_STAMP(3)
     // ---- segment 1: the fused 1x1 shortcut (2-4 iterations): raw centre pixels, plain staged loop ---------------------
     for (int c2 = 0; c2 < nchunks2; ++c2) {
         uint4 r0, r1, r2, r3; unsigned m0, m1, m2, m3;
@@ -277,7 +328,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
         *reinterpret_cast<uint4*>(smem + piece1_dst(2, 0)) = r2; *reinterpret_cast<uint4*>(smem + piece1_dst(3, 0)) = r3;
         V2_STORE_W(0, wa0, wa1);
         __syncthreads();
-        const char* ha_ = smem + (V2_HE + 1) * ROWB;          // centre tap of halo buffer 0
+        const char* ha_ = smem + HPITCH + ROWB;               // centre tap of halo buffer 0
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
 #pragma unroll
@@ -291,6 +342,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
 #undef V2_MFMA
 #undef V2_STORE_W
 
+    V2_STAMP(4)
     // ------------------------------ epilogue (as conv_kernel: per-wave LDS transpose, 16-byte I/O) -------------------
     constexpr int STG_LD = NW + 4;
     constexpr int STG_WAVE = 32 * STG_LD * 4;
@@ -301,17 +353,6 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
     float* const red = reinterpret_cast<float*>(smem + 8 * STG_WAVE);     // [WM][BN][2]
     TOUT* out = (TOUT*)p.out;
     const TOUT* res = (const TOUT*)p.res;
-    float addv[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = n0 + wn * NW + j * 32 + (lane & 31);
-        float add = 0.f;
-        if (co < p.Cout) {
-            if (p.bias) add += p.bias[co];
-            if (p.temb) add += p.temb[(size_t)b * p.temb_bstride + co];
-        }
-        addv[j] = add;
-    }
     const int ch = lane % CPR;
     const int co0 = n0 + wn * NW + ch * CH;
     const bool cok = co0 < p.Cout;
@@ -343,6 +384,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
                 stg[row * STG_LD + j * 32 + (lane & 31)] = acc[i][j][r] + addv[j];
             }
         __builtin_amdgcn_wave_barrier();
+        V2_STAMP(41 + 2 * i)
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
             const int row = (q * 64 + lane) / CPR;
@@ -383,6 +425,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
             }
         }
         __builtin_amdgcn_wave_barrier();
+        V2_STAMP(42 + 2 * i)
     }
     if (p.stats) {
 #pragma unroll
@@ -409,12 +452,14 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
             }
         }
     }
+    V2_STAMP(5)
 }
 
 template <typename TIN, typename TOUT, int CK, bool ACT>
 static void v2_launch_t(const ConvArgs& a, hipStream_t s) {
     constexpr int ROWB = CK * (int)sizeof(TIN) + 16;
-    constexpr int MAIN = 2 * V2_HALO * ROWB + 2 * V2_BN * ROWB + 512 * 16;
+    constexpr int HPITCH = (V2_HE * ROWB / 16 + 15) / 16 * 16 * 16;
+    constexpr int MAIN = 2 * V2_HE * HPITCH + 2 * V2_BN * ROWB + 512 * 16;
     constexpr int EPI = 8 * 32 * (64 + 4) * 4 + 4 * V2_BN * 2 * 4;
     constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
     static bool attr_set = false;
@@ -438,6 +483,29 @@ void launch_conv_v2(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     static const int dbg = getenv("USE_HIP_DBG") ? atoi(getenv("USE_HIP_DBG")) : 0;
     a.dbg = dbg;
+    static unsigned long long* trace_buf = nullptr;
+    if (getenv("USE_HIP_TRACE")) {           // bring-up only: print the phase timeline of the first eligible launch of a given shape
+        static int printed = 0;
+        const int want_c = atoi(getenv("USE_HIP_TRACE"));
+        if (!trace_buf) { (void)hipMalloc((void**)&trace_buf, 512 * 8); }
+        if (!printed && a.H == 512 && a.C0 + a.C1 == want_c) {
+            (void)hipMemsetAsync(trace_buf, 0, 512 * 8, s);
+            a.trace = trace_buf;
+            if (a.in_dtype == DT_BF16) { a.act ? v2_launch_t<__bf16, __bf16, 64, true>(a, s) : v2_launch_t<__bf16, __bf16, 64, false>(a, s); }
+            (void)hipStreamSynchronize(s);
+            unsigned long long hbuf[512];
+            (void)hipMemcpy(hbuf, trace_buf, sizeof hbuf, hipMemcpyDeviceToHost);
+            for (int g = 0; g < 2; ++g) {
+                unsigned long long prev = hbuf[g * 256 + 1];
+                for (int i = 0; i < 120 && hbuf[g * 256 + 2 * i]; ++i) {
+                    fprintf(stderr, "[trace G%d] id %3llu  +%6llu\n", g, hbuf[g * 256 + 2 * i], hbuf[g * 256 + 2 * i + 1] - prev);
+                    prev = hbuf[g * 256 + 2 * i + 1];
+                }
+            }
+            printed = 1;
+            a.trace = nullptr;
+        }
+    }
     if (a.in_dtype == DT_BF16) { a.act ? v2_launch_t<__bf16, __bf16, 64, true>(a, s) : v2_launch_t<__bf16, __bf16, 64, false>(a, s); }
     else                       { a.act ? v2_launch_t<float, float, 32, true>(a, s) : v2_launch_t<float, float, 32, false>(a, s); }
 }

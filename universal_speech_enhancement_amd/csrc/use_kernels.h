@@ -41,6 +41,7 @@ struct ConvArgs {
     float* stats;           // or null
     int B, H, W, Cout, ntaps;
     int dbg;                // ablation bits for kernel bring-up (0 in production)
+    unsigned long long* trace;   // optional: s_memtime stamps of workgroup 0 (kernel bring-up), else null
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
 // software-pipelined variant for large maps (use_conv_v2.hip); launch_conv dispatches to it when eligible
