@@ -182,10 +182,10 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
 
     // ---- weights: 2 pieces per thread per (tap, chunk) slab; 32-bit element offsets from a uniform slab pointer -------
     const int wrow0 = tid / PARTS, wrow1 = (tid + 512) / PARTS;
-    const unsigned wo0 = wrow0 * Ctot + part * VEC, wo1 = wrow1 * Ctot + part * VEC;          // segment 0 (ld = Ctot)
+    const unsigned wo0 = wrow0 * 9 * Ctot + part * VEC, wo1 = wrow1 * 9 * Ctot + part * VEC;  // rows are 9*Ctot apart
     const int wdst0 = 2 * HALO_BYTES + wrow0 * ROWB + part * 16, wdst1 = 2 * HALO_BYTES + wrow1 * ROWB + part * 16;
-    const size_t tapstride = (size_t)p.cout_pad * Ctot;                                       // elements between taps
-    const TIN* const wseg0 = (const TIN*)p.w + (size_t)n0 * Ctot;
+    const size_t tapstride = (size_t)Ctot;                                                    // elements between taps
+    const TIN* const wseg0 = (const TIN*)p.w + (size_t)n0 * 9 * Ctot;
     // weights of iteration (chunk CC, tap TT) -> R0/R1 ; TT may run past 8 (wraps into the next chunk)
 #define V2_LOAD_W(CC, TT, R0, R1)                                                                                    \
     {                                                                                                                \

@@ -258,7 +258,7 @@ static void pack_conv(const use_handle* h, const ConvW& w, char* blob) {
             for (int ci = 0; ci < w.cin; ++ci) {
                 // reference conv weight [cout][cin][kh][kw]; NIN W is [cin][cout] (layers.py:639-650)
                 const float v = w.nin ? src[(size_t)ci * w.cout + co] : src[((size_t)co * w.cin + ci) * w.ntaps + tap];
-                const size_t o = ((size_t)tap * w.cout_pad + co) * w.cin + ci;
+                const size_t o = ((size_t)co * w.ntaps + tap) * w.cin + ci;   // [cout][tap][cin]: see use_kernels.h
                 if (w.w_dtype == DT_F32) ((float*)dst)[o] = v; else ((uint16_t*)dst)[o] = f32_to_bf16(v);
             }
     memcpy(blob + w.b_off, bias.data(), (size_t)w.cout * 4);

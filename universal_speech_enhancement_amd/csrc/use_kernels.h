@@ -24,9 +24,11 @@ struct ConvArgs {
     const void* src0; const void* src1; int C0; int C1; int in_dtype;
     const float* coef;      // [B][C0+C1][2] (a, b) or null
     int act;                // 0: none, 1: SiLU (after the affine)
-    const void* w;          // packed [ntaps][CoutPad][C0+C1] in in_dtype
+    const void* w;          // packed [CoutPad][ntaps][C0+C1] in in_dtype: the 128 rows of one (tap, chunk) slab lie
+                            // ntaps*Cin*2 bytes apart, i.e. on different pages / L2 channels (all CUs fetch the same slab
+                            // at about the same time)
     int cout_pad;
-    // optional second K segment: + conv1x1(concat(x0[XC0], x1[XC1])) with weights w2 [1][CoutPad][XC0+XC1]
+    // optional second K segment: + conv1x1(concat(x0[XC0], x1[XC1])) with weights w2 [CoutPad][1][XC0+XC1]
     // (the res-block shortcut Conv_2 fused into Conv_1; raw input, no affine / activation)
     const void* x0; const void* x1; int XC0; int XC1; const void* w2;
     const float* bias;      // [Cout] or null

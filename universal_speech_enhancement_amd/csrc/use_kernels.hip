@@ -140,14 +140,15 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
     if (WPT > (Q)) {                                                                                           \
         const int idx = tid + (Q)*256;                                                                         \
         if (!WGUARD || idx < BN * PARTS)                                                                       \
-            DST = *reinterpret_cast<const uint4*>(wb_ + (size_t)(idx / PARTS) * wld_ + (idx % PARTS) * VEC);   \
+            DST = *reinterpret_cast<const uint4*>(wb_ + (size_t)(idx / PARTS) * wrs_ + (idx % PARTS) * VEC);   \
     }
 #define USE_LOAD_W(IT)                                                                                         \
     {                                                                                                          \
         const bool seg1_ = (IT) >= nit1;                                                                       \
         const int chunk_ = seg1_ ? (IT)-nit1 : (IT) / p.ntaps, tap_ = seg1_ ? 0 : (IT)-chunk_ * p.ntaps;       \
         const int wld_ = seg1_ ? XCtot : Ctot;                                                                 \
-        const TIN* wb_ = (seg1_ ? (const TIN*)p.w2 : (const TIN*)p.w) + ((size_t)tap_ * p.cout_pad + n0) * wld_ + chunk_ * CK; \
+        const int wrs_ = seg1_ ? wld_ : p.ntaps * wld_;            /* row (cout) stride in elements */                  \
+        const TIN* wb_ = (seg1_ ? (const TIN*)p.w2 : (const TIN*)p.w) + (size_t)n0 * wrs_ + (size_t)tap_ * wld_ + chunk_ * CK; \
         USE_LOAD_Q(0, wr0) USE_LOAD_Q(1, wr1) USE_LOAD_Q(2, wr2) USE_LOAD_Q(3, wr3)                            \
     }
 #define USE_STORE_Q(Q, SRC, BUF)                                                                               \
