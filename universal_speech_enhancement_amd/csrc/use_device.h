@@ -14,7 +14,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 template <bool ACCURATE>
 DEVI float silu_f(float x) {
     if (ACCURATE) return x / (1.0f + expf(-x));
-    return x * __frcp_rn(1.0f + __expf(-x));
+    // bf16 storage: v_exp_f32 / v_rcp_f32 approximations (1 ulp-class) are far below the bf16 rounding of the result;
+    // __frcp_rn would expand to a ~10-instruction IEEE division sequence
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -437,21 +437,96 @@ __global__ __launch_bounds__(256) void fir_kernel(const T* __restrict__ src, con
     }
 }
 
+// Up x2, one thread per 2x2 INPUT neighbourhood {m,m+1} x {n,n+1} (8 or 4 channels): it owns the 2x2 output block
+// rows {2m+1, 2m+2} x cols {2n+1, 2n+2}, which depends on exactly those four inputs -> each input is normalised and
+// activated 4x less often than in the output-stationary form (the kernel was VALU-bound on SiLU).
+template <typename T>
+__global__ __launch_bounds__(256) void fir_up_blk_kernel(const T* __restrict__ src, const float* __restrict__ coef,
+                                                         int act, T* __restrict__ out_act, T* __restrict__ out_raw,
+                                                         int B, int H, int W, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    constexpr bool ACC = sizeof(T) == 4;
+    const int cv = C / VEC;
+    const long total = (long)B * (H + 1) * (W + 1) * cv;
+    const bool want_act = out_act != nullptr;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * VEC;
+        long r = idx / cv;
+        const int n = (int)(r % (W + 1)) - 1; r /= (W + 1);
+        const int m = (int)(r % (H + 1)) - 1;
+        const int b = (int)(r / (H + 1));
+        float ca[VEC], cb[VEC];
+        if (want_act && coef) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { ca[k] = coef[((size_t)b * C + c + k) * 2]; cb[k] = coef[((size_t)b * C + c + k) * 2 + 1]; }
+        }
+        float xr[2][2][VEC], xa[2][2][VEC];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int y = m + dy, x = n + dx;
+                if (y >= 0 && y < H && x >= 0 && x < W) {
+                    Vec16<T>::load(src + ((size_t)(b * H + y) * W + x) * C + c, xr[dy][dx]);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        float u = (want_act && coef) ? fmaf(xr[dy][dx][k], ca[k], cb[k]) : xr[dy][dx][k];
+                        xa[dy][dx][k] = (want_act && act) ? silu_f<ACC>(u) : u;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) { xr[dy][dx][k] = 0.f; xa[dy][dx][k] = 0.f; }
+                }
+            }
+        // output row 2m+1+py takes input rows (m, m+1) with weights (.75,.25) for py=0 and (.25,.75) for py=1
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const int oy = 2 * m + 1 + py, ox = 2 * n + 1 + px;
+                if (oy < 0 || oy >= 2 * H || ox < 0 || ox >= 2 * W) continue;
+                const float wy0 = py ? 0.25f : 0.75f, wy1 = 1.f - wy0, wx0 = px ? 0.25f : 0.75f, wx1 = 1.f - wx0;
+                float orr[VEC], oa[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    orr[k] = wy0 * (wx0 * xr[0][0][k] + wx1 * xr[0][1][k]) + wy1 * (wx0 * xr[1][0][k] + wx1 * xr[1][1][k]);
+                    oa[k] = wy0 * (wx0 * xa[0][0][k] + wx1 * xa[0][1][k]) + wy1 * (wx0 * xa[1][0][k] + wx1 * xa[1][1][k]);
+                }
+                const size_t o = ((size_t)(b * 2 * H + oy) * (2 * W) + ox) * C + c;
+                if (out_raw) Vec16<T>::store(out_raw + o, orr);
+                if (want_act) Vec16<T>::store(out_act + o, oa);
+            }
+    }
+}
+
 template <bool UP>
 static void fir_launch(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
                        int H, int W, int C, hipStream_t s) {
-    const int OH = UP ? 2 * H : H / 2, OW = UP ? 2 * W : W / 2;
     const int vec = dtype == DT_F32 ? 4 : 8;
-    const long total = (long)B * OH * OW * (C / vec);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    if (blocks < 1) blocks = 1;
-    if (dtype == DT_F32)
-        hipLaunchKernelGGL((fir_kernel<float, UP>), dim3(blocks), dim3(256), 0, s, (const float*)src, coef, act,
-                           (float*)out_act, (float*)out_raw, B, H, W, C);
-    else
-        hipLaunchKernelGGL((fir_kernel<__bf16, UP>), dim3(blocks), dim3(256), 0, s, (const __bf16*)src, coef, act,
-                           (__bf16*)out_act, (__bf16*)out_raw, B, H, W, C);
+    if (UP) {
+        const long total = (long)B * (H + 1) * (W + 1) * (C / vec);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        if (blocks < 1) blocks = 1;
+        if (dtype == DT_F32)
+            hipLaunchKernelGGL((fir_up_blk_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)src, coef, act,
+                               (float*)out_act, (float*)out_raw, B, H, W, C);
+        else
+            hipLaunchKernelGGL((fir_up_blk_kernel<__bf16>), dim3(blocks), dim3(256), 0, s, (const __bf16*)src, coef, act,
+                               (__bf16*)out_act, (__bf16*)out_raw, B, H, W, C);
+    } else {   // (an LDS-tiled variant that activates each input once measured slower: 64-byte input segments, 32 LDS reads/thread)
+        const int OH = H / 2, OW = W / 2;
+        const long total = (long)B * OH * OW * (C / vec);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        if (blocks < 1) blocks = 1;
+        if (dtype == DT_F32)
+            hipLaunchKernelGGL((fir_kernel<float, false>), dim3(blocks), dim3(256), 0, s, (const float*)src, coef, act,
+                               (float*)out_act, (float*)out_raw, B, H, W, C);
+        else
+            hipLaunchKernelGGL((fir_kernel<__bf16, false>), dim3(blocks), dim3(256), 0, s, (const __bf16*)src, coef, act,
+                               (__bf16*)out_act, (__bf16*)out_raw, B, H, W, C);
+    }
 }
 void launch_fir_up2(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
                     int H, int W, int C, hipStream_t s) { fir_launch<true>(src, dtype, coef, act, out_act, out_raw, B, H, W, C, s); }
