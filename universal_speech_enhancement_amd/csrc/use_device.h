@@ -73,4 +73,26 @@ template <> struct Mfma<float> {
     DEVI static f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 };
 
+// Sum over the lanes {l, l+S, l+2S, ...} of a wave (S = 4, 8 or 16) with VALU cross-lane ops only (DPP row rotate,
+// v_permlane16_swap, v_permlane32_swap) -- no LDS round trips (ds_bpermute) on the epilogue's critical path.
+template <int S>
+DEVI float reduce_lanes_stride(float v) {
+    static_assert(S == 4 || S == 8 || S == 16, "stride");
+    if (S <= 4)   // lanes i, i+4, i+8, i+12 of each 16-lane row: rotate by 4, then by 8 (sums are rotation-invariant)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    if (S <= 8)   // row_ror:8
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    {             // xor 16: after the swap the two results hold (row0,row0,row2,row2) and (row1,row1,row3,row3)
+        const int vi = __builtin_bit_cast(int, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(vi, vi, false, false);
+        v = __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+    }
+    {             // xor 32
+        const int vi = __builtin_bit_cast(int, v);
+        const auto r = __builtin_amdgcn_permlane32_swap(vi, vi, false, false);
+        v = __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+    }
+    return v;
+}
+
 }  // namespace use

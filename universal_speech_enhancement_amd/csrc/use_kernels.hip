@@ -277,10 +277,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
     }
     if (p.stats) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-#pragma unroll
-            for (int o = CPR; o < 64; o <<= 1) { st_s[c] += __shfl_xor(st_s[c], o); st_q[c] += __shfl_xor(st_q[c], o); }
-        }
+        for (int c = 0; c < CH; ++c) { st_s[c] = reduce_lanes_stride<CPR>(st_s[c]); st_q[c] = reduce_lanes_stride<CPR>(st_q[c]); }
         if (lane < CPR) {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
