@@ -315,29 +315,40 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
 #undef V2_LOAD_W
 
     V2_STAMP(3)
-    // ---- segment 1: the fused 1x1 shortcut (2-4 iterations): raw centre pixels, plain staged loop ---------------------
-    for (int c2 = 0; c2 < nchunks2; ++c2) {
+    // ---- segment 1: the fused 1x1 shortcut (2-4 iterations): raw centre pixels; double-buffered, one barrier per
+    // iteration, the loads of chunk c2+1 fly behind the fragment reads + MFMAs of chunk c2 -------------------------------
+    if (nchunks2 > 0) {
         uint4 r0, r1, r2, r3; unsigned m0, m1, m2, m3;
-        m0 = load_piece1(c2, 0, r0); m1 = load_piece1(c2, 1, r1); m2 = load_piece1(c2, 2, r2); m3 = load_piece1(c2, 3, r3);
-        const TIN* wb_ = (const TIN*)p.w2 + (size_t)n0 * XCtot + c2 * CK;
-        wa0 = *reinterpret_cast<const uint4*>(wb_ + wrow0 * XCtot + part * VEC);
-        wa1 = *reinterpret_cast<const uint4*>(wb_ + wrow1 * XCtot + part * VEC);
-        r0.x &= m0; r0.y &= m0; r0.z &= m0; r0.w &= m0; r1.x &= m1; r1.y &= m1; r1.z &= m1; r1.w &= m1;
-        r2.x &= m2; r2.y &= m2; r2.z &= m2; r2.w &= m2; r3.x &= m3; r3.y &= m3; r3.z &= m3; r3.w &= m3;
-        *reinterpret_cast<uint4*>(smem + piece1_dst(0, 0)) = r0; *reinterpret_cast<uint4*>(smem + piece1_dst(1, 0)) = r1;
-        *reinterpret_cast<uint4*>(smem + piece1_dst(2, 0)) = r2; *reinterpret_cast<uint4*>(smem + piece1_dst(3, 0)) = r3;
-        V2_STORE_W(0, wa0, wa1);
-        __syncthreads();
-        const char* ha_ = smem + HPITCH + ROWB;               // centre tap of halo buffer 0
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[kk][i] = MF::ld(ha_ + a_base[i] + kk * MF::KM * (int)sizeof(TIN));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[kk][j] = MF::ld(smem + b_base[j] + kk * MF::KM * (int)sizeof(TIN));
+#define V2_SC_LOAD(C2)                                                                                        \
+        {                                                                                                     \
+            m0 = load_piece1(C2, 0, r0); m1 = load_piece1(C2, 1, r1); m2 = load_piece1(C2, 2, r2); m3 = load_piece1(C2, 3, r3); \
+            const TIN* wb_ = (const TIN*)p.w2 + (size_t)n0 * XCtot + (C2)*CK;                                 \
+            wa0 = *reinterpret_cast<const uint4*>(wb_ + wrow0 * XCtot + part * VEC);                          \
+            wa1 = *reinterpret_cast<const uint4*>(wb_ + wrow1 * XCtot + part * VEC);                          \
         }
-        V2_MFMA(nchunks, 0)
-        __syncthreads();
+        V2_SC_LOAD(0)
+        for (int c2 = 0; c2 < nchunks2; ++c2) {
+            const int buf = c2 & 1;
+            r0.x &= m0; r0.y &= m0; r0.z &= m0; r0.w &= m0; r1.x &= m1; r1.y &= m1; r1.z &= m1; r1.w &= m1;
+            r2.x &= m2; r2.y &= m2; r2.z &= m2; r2.w &= m2; r3.x &= m3; r3.y &= m3; r3.z &= m3; r3.w &= m3;
+            *reinterpret_cast<uint4*>(smem + piece1_dst(0, buf)) = r0; *reinterpret_cast<uint4*>(smem + piece1_dst(1, buf)) = r1;
+            *reinterpret_cast<uint4*>(smem + piece1_dst(2, buf)) = r2; *reinterpret_cast<uint4*>(smem + piece1_dst(3, buf)) = r3;
+            V2_STORE_W(buf, wa0, wa1);
+            __syncthreads();
+            if (c2 + 1 < nchunks2) V2_SC_LOAD(c2 + 1)
+            const char* ha_ = smem + buf * HALO_BYTES + HPITCH + ROWB;        // centre tap
+            const char* wb2_ = smem + buf * W_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[kk][i] = MF::ld(ha_ + a_base[i] + kk * MF::KM * (int)sizeof(TIN));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[kk][j] = MF::ld(wb2_ + b_base[j] + kk * MF::KM * (int)sizeof(TIN));
+            }
+            V2_MFMA(nchunks, 0)
+        }
+#undef V2_SC_LOAD
+        __syncthreads();                                     // the epilogue re-uses the LDS
     }
 #undef V2_MFMA
 #undef V2_STORE_W
