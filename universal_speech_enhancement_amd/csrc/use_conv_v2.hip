@@ -155,12 +155,19 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
             for (int k = 0; k < VEC; ++k) { ca[k] = cf[2 * k]; cb[k] = cf[2 * k + 1]; }
         }
     };
-    auto src_ptr0 = [&](int chunk, int pixoff) -> const uint4* {
+    // Global loads of the main loop are buffer loads: a 4-SGPR descriptor of the tensor, a uniform SGPR offset and a 32-bit
+    // per-lane VGPR offset - half the address traffic of a 64-bit-pointer global_load per issue.
+    auto buf_ld = [&](const void* base, unsigned voff, unsigned soff) -> uint4 {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    };
+    auto src_ld0 = [&](int chunk, int pixoff) -> uint4 {
         const int c_glob = chunk * CK;
         const TIN* src; int Cs, c_loc;
         if (c_glob < p.C0) { src = (const TIN*)p.src0; Cs = p.C0; c_loc = c_glob; }
         else               { src = (const TIN*)p.src1; Cs = p.C1; c_loc = c_glob - p.C0; }
-        return reinterpret_cast<const uint4*>(src + (size_t)pixoff * Cs + c_loc + part * VEC);
+        const unsigned voff = (unsigned)pixoff * (unsigned)(Cs * (int)sizeof(TIN)) + (unsigned)(part * 16);
+        return buf_ld(src, voff, (unsigned)(c_loc * (int)sizeof(TIN)));
     };
     // ---- segment-1 (shortcut) pieces: centre 16x16 pixels only, 4 per thread, raw ---------------------------------
     auto load_piece1 = [&](int chunk2, int q, uint4& raw) -> unsigned {
@@ -183,8 +190,8 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
     // ---- weights: 2 pieces per thread per (tap, chunk) slab; 32-bit element offsets from a uniform slab pointer -------
     const int wrow0 = tid / PARTS, wrow1 = (tid + 512) / PARTS;
     const unsigned wo0 = wrow0 * 9 * Ctot + part * VEC, wo1 = wrow1 * 9 * Ctot + part * VEC;  // rows are 9*Ctot apart
+    const unsigned wob0 = wo0 * (unsigned)sizeof(TIN), wob1 = wo1 * (unsigned)sizeof(TIN);    // the same in bytes
     const int wdst0 = 2 * HALO_BYTES + wrow0 * ROWB + part * 16, wdst1 = 2 * HALO_BYTES + wrow1 * ROWB + part * 16;
-    const size_t tapstride = (size_t)Ctot;                                                    // elements between taps
     const TIN* const wseg0 = (const TIN*)p.w + (size_t)n0 * 9 * Ctot;
     // weights of iteration (chunk CC, tap TT) -> R0/R1 ; TT may run past 8 (wraps into the next chunk)
 #define V2_LOAD_W(CC, TT, R0, R1)                                                                                    \
@@ -192,8 +199,8 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
         const int cw_ = (TT) > 8 ? (CC) + 1 : (CC);                                                                  \
         const int tw_ = (TT) > 8 ? (TT)-9 : (TT);                                                                    \
         if (cw_ < nchunks) {                                                                                         \
-            const TIN* wb_ = wseg0 + tw_ * tapstride + cw_ * CK;                                                     \
-            R0 = *reinterpret_cast<const uint4*>(wb_ + wo0); R1 = *reinterpret_cast<const uint4*>(wb_ + wo1);        \
+            const unsigned so_ = (unsigned)(tw_ * Ctot + cw_ * CK) * (unsigned)sizeof(TIN);                          \
+            R0 = buf_ld(wseg0, wob0, so_); R1 = buf_ld(wseg0, wob1, so_);                                            \
         }                                                                                                            \
     }
 #define V2_STORE_W(BUF, R0, R1)                                                                     \
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
         V2_LOAD_W(0, 0, w00, w01);
         V2_LOAD_W(0, 1, wa0, wa1);                           // weights of iteration 1, stored by LDS(0)
 #pragma unroll
-        for (int j = 0; j < PIECE_ITERS; ++j) raw[j] = *src_ptr0(0, ppix[j]);
+        for (int j = 0; j < PIECE_ITERS; ++j) raw[j] = src_ld0(0, ppix[j]);
         load_coef(0);
         V2_STORE_W(0, w00, w01);
 #pragma unroll
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
         if ((T) < PIECE_ITERS && next_) {                                                                            \
             if ((T) == 0) load_coef(cc_ + 1);                                                                        \
             constexpr int k_ = (T) < PIECE_ITERS ? (T) : 0;                                                          \
-            hL = *src_ptr0(cc_ + 1, ppix[k_]);                                                                       \
+            hL = src_ld0(cc_ + 1, ppix[k_]);                                                                           \
         }                                                                                                            \
         V2_LOAD_W(cc_, (T) + 2, wa0, wa1);                                                                           \
         V2_STAMPF(200 + (T))                                                                                          \
@@ -488,6 +495,7 @@ bool conv_v2_eligible(const ConvArgs& a) {
 }
 
 void launch_conv_v2(const ConvArgs& a0, hipStream_t s) {
+    static const bool use_v3 = getenv("USE_HIP_V3") != nullptr && atoi(getenv("USE_HIP_V3")) != 0;
     ConvArgs a = a0;
     static const int dbg = getenv("USE_HIP_DBG") ? atoi(getenv("USE_HIP_DBG")) : 0;
     a.dbg = dbg;
@@ -499,7 +507,8 @@ void launch_conv_v2(const ConvArgs& a0, hipStream_t s) {
         if (!printed && a.H == 512 && a.C0 + a.C1 == want_c) {
             (void)hipMemsetAsync(trace_buf, 0, 512 * 8, s);
             a.trace = trace_buf;
-            if (a.in_dtype == DT_BF16) { a.act ? v2_launch_t<__bf16, __bf16, 64, true>(a, s) : v2_launch_t<__bf16, __bf16, 64, false>(a, s); }
+            if (use_v3) launch_conv_v3(a, s);
+            else if (a.in_dtype == DT_BF16) { a.act ? v2_launch_t<__bf16, __bf16, 64, true>(a, s) : v2_launch_t<__bf16, __bf16, 64, false>(a, s); }
             (void)hipStreamSynchronize(s);
             unsigned long long hbuf[512];
             (void)hipMemcpy(hbuf, trace_buf, sizeof hbuf, hipMemcpyDeviceToHost);
@@ -514,6 +523,7 @@ void launch_conv_v2(const ConvArgs& a0, hipStream_t s) {
             a.trace = nullptr;
         }
     }
+    if (use_v3) { launch_conv_v3(a, s); return; }
     if (a.in_dtype == DT_BF16) { a.act ? v2_launch_t<__bf16, __bf16, 64, true>(a, s) : v2_launch_t<__bf16, __bf16, 64, false>(a, s); }
     else                       { a.act ? v2_launch_t<float, float, 32, true>(a, s) : v2_launch_t<float, float, 32, false>(a, s); }
 }

@@ -49,6 +49,7 @@ void launch_conv(const ConvArgs& a, hipStream_t s);
 // software-pipelined variant for large maps (use_conv_v2.hip); launch_conv dispatches to it when eligible
 bool conv_v2_eligible(const ConvArgs& a);
 void launch_conv_v2(const ConvArgs& a, hipStream_t s);
+void launch_conv_v3(const ConvArgs& a, hipStream_t s);   // wave-specialised variant (use_conv_v3.hip), same tiles as v2
 // number of per-image statistics tiles the kernel chosen for `a` writes (stats layout [B][tiles][Cout][2])
 inline int conv_out_tiles(const ConvArgs& a) { return conv_v2_eligible(a) ? conv_v2_tiles(a.H, a.W) : tiles_per_image(a.H, a.W); }
 
