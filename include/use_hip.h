@@ -57,6 +57,9 @@ typedef struct use_sampler_config {
     int use_graph;         /* 1: capture the whole loop in a hipGraph and replay it                    */
 } use_sampler_config;
 
+/* Process-wide tuning knobs (no reference counterpart).  "conv_v4_min_blocks": smallest per-image grid (workgroups) the
+ * wide-tile convolution kernel is selected for, default 128; results do not depend on it beyond rounding order. */
+int use_set_option(const char* name, long long value);
 const char* use_last_error(void);
 const char* use_version(void);
 

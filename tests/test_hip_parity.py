@@ -63,6 +63,23 @@ def test_score_matches_reference_golden(golden_dir, engines, prec, tol):
         assert err < tol, (prec, tag, err)
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", 6e-2)])
+def test_score_golden_with_wide_tile_kernel_forced(golden_dir, engines, prec, tol):
+    """conv_v4_kernel is normally reserved for maps of >= 128 workgroups per image; force it onto the golden-vector shapes."""
+    from universal_speech_enhancement_amd.hip_engine import set_option
+    g = dict(np.load(os.path.join(golden_dir, "forward_large.npz")))
+    x = torch.from_numpy(g["x"]).cuda()
+    set_option("conv_v4_min_blocks", 1)
+    try:
+        out = engines[prec].score(x[:, 0:1].contiguous(), x[:, 1:2].contiguous(), torch.from_numpy(g["t_a"]).cuda())
+    finally:
+        set_option("conv_v4_min_blocks", 128)
+    err = _relmax(out, -torch.from_numpy(g["out_a"]))
+    assert err < tol, (prec, err)
+    with pytest.raises(Exception):
+        set_option("no_such_option", 1)
+
+
 def test_intermediate_taps_match_oracle_fp32(golden_dir, engines, sd_np):
     g = dict(np.load(os.path.join(golden_dir, "forward_large.npz")))
     x = torch.from_numpy(g["x"])

@@ -37,6 +37,7 @@ _lib = None
 # every symbol declared in include/use_hip.h: (restype, argtypes)
 _vp, _i, _i64, _u64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
 SYMBOLS = {
+    "use_set_option": (C.c_int, [C.c_char_p, C.c_longlong]),
     "use_last_error": (C.c_char_p, []),
     "use_version": (C.c_char_p, []),
     "use_create": (_i, [C.POINTER(UseConfig), _i, C.POINTER(_vp)]),

@@ -1,0 +1,493 @@
+// conv_v4_kernel: the wide-tile variant of conv_v2_kernel for the large feature maps.  Same arithmetic, schedule idea
+// and argument struct; different geometry, chosen to cut the per-MFMA cost of everything that is not an MFMA:
+//
+//   * one workgroup = 8 waves computes a 16-row x 32-column pixel tile x 128 output channels; every wave owns two full
+//     tile rows (64 pixels) x all 128 channels = 2x4 MFMA 32x32 tiles (128 accumulator VGPRs).  A weight slab is thus
+//     used for 512 pixels instead of 256: half the vector-memory instructions, LDS writes and L2->L1 bytes per FLOP,
+//     and 12 instead of 16 fragment reads per 16 MFMAs.  (Measured on conv_v2/conv_v3: beside running MFMAs a
+//     vector-memory instruction costs its wave 100-260 cycles of issue time - the count per MFMA is what matters.)
+//   * K is walked in chunks of 32 input channels (64-byte pixel rows, padded to 80 B in LDS), so the two halo buffers
+//     of the twice-as-large tile still fit: LDS = 2 x 48,960 B halo + 2 x 10,240 B weight slabs.
+//   * weights come from a second, slab-major copy in the blob ([tap][chunk][cout][32]): one (tap, chunk) slab is 8 KB
+//     contiguous, one 16-byte piece per thread.
+//
+// Ping-pong as in conv_v2: waves 0-3 and 4-7 (one of each per SIMD) alternate between an "LDS phase" (12 fragment
+// reads, the staging stores and global-load issue) and an "MFMA phase" (16 MFMAs with the GroupNorm+SiLU transform of
+// one halo piece on the VALU in their shadow), one s_barrier per phase.
+#include "use_kernels.h"
+#include "use_device.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace use {
+
+constexpr int V4_TW = 32, V4_TH = 16;             // tile: 16 rows x 32 columns
+constexpr int V4_HW = V4_TW + 2, V4_HH = V4_TH + 2;
+constexpr int V4_BN = 128;
+
+template <typename TIN, bool ACT>
+DEVI uint4 v4_transform(const uint4 raw, const unsigned mask, const float (&ca)[16 / sizeof(TIN)],
+                        const float (&cb)[16 / sizeof(TIN)]) {
+    constexpr int VEC = 16 / sizeof(TIN);
+    float v[VEC];
+    Vec16<TIN>::load(reinterpret_cast<const TIN*>(&raw), v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        v[k] = fmaf(v[k], ca[k], cb[k]);
+        if (ACT) {
+            if (sizeof(TIN) == 4) v[k] = v[k] / (1.0f + expf(-v[k]));        // fp32 parity mode: accurate
+            else v[k] = v[k] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[k] * -1.44269504088896341f));
+        }
+    }
+    uint4 o = Vec16<TIN>::pack(v);
+    o.x &= mask; o.y &= mask; o.z &= mask; o.w &= mask;
+    return o;
+}
+
+template <typename TIN, typename TOUT, int CK, bool ACT>
+__global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
+    typedef Mfma<TIN> MF;
+    constexpr int VEC = 16 / sizeof(TIN);
+    constexpr int PARTS = CK / VEC;                          // 16-byte pieces per pixel row of a chunk (4)
+    constexpr int ROWB = CK * (int)sizeof(TIN) + 16;         // 80: conflict-free for the 16-lane ds_read_b128 groups
+    constexpr int BN = V4_BN, TM = 2, TN = 4;
+    constexpr int KSTEPS = CK / MF::KM;
+    constexpr int KB = MF::KM * (int)sizeof(TIN);
+    constexpr int HPITCH = V4_HW * ROWB;                     // a 32-pixel fragment never crosses a halo row
+    constexpr int HALO_BYTES = V4_HH * HPITCH, W_BYTES = BN * ROWB;
+    constexpr int MAIN_BYTES = 2 * HALO_BYTES + 2 * W_BYTES;
+    constexpr int NPIECE = V4_HH * V4_HW * PARTS;            // 2448 pieces per halo chunk
+    constexpr int PIECE_ITERS = (NPIECE + 511) / 512;        // 5
+    static_assert(PARTS == 4 && PIECE_ITERS == 5 && BN * PARTS == 512, "v4 staging layout");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [2][HALO_BYTES] halo tiles, [2][W_BYTES] weight slabs, [512][16] dummy slots (threads without a piece)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    int tile = blockIdx.x;                                   // XCD-aware order: contiguous band of tiles per XCD
+    if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int tiles_x = (p.W + V4_TW - 1) / V4_TW;
+    const int ty0 = (tile / tiles_x) * V4_TH, tx0 = (tile % tiles_x) * V4_TW;
+    const int n0 = blockIdx.y * BN;
+    const int Ctot = p.C0 + p.C1, nchunks = Ctot / CK;
+    const int XCtot = p.XC0 + p.XC1, nchunks2 = XCtot / CK;
+    const int part = tid & (PARTS - 1);
+
+    float addv[TN];                                          // bias + time-embedding bias of this lane's channels
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + j * 32 + (lane & 31);
+        float add = 0.f;
+        if (co < p.Cout) {
+            if (p.bias) add += p.bias[co];
+            if (p.temb) add += p.temb[(size_t)b * p.temb_bstride + co];
+        }
+        addv[j] = add;
+    }
+
+#ifdef USE_HIP_TRACE_BUILD   /* bring-up: lane 0 of waves 0 and 4 of workgroup 0 stamp the cycle counter at coarse boundaries */
+    const bool tracing = p.trace != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave & 3) == 0;
+    int trace_n = 0;
+#define V4_STAMP(ID)                                                                                   \
+    if (tracing && trace_n < 120) {                                                                    \
+        p.trace[(wave >> 2) * 256 + 2 * trace_n] = (unsigned long long)(ID);                           \
+        p.trace[(wave >> 2) * 256 + 2 * trace_n + 1] = __builtin_readcyclecounter(); ++trace_n;        \
+    }
+#else
+#define V4_STAMP(ID)
+#endif
+    V4_STAMP(1)
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int a_base[TM], b_base[TN];                              // LDS byte offsets of this lane's fragments
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+        a_base[i] = (wave * 2 + i) * HPITCH + (lane & 31) * ROWB + (lane >> 5) * MF::KPL * (int)sizeof(TIN);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        b_base[j] = 2 * HALO_BYTES + (j * 32 + (lane & 31)) * ROWB + (lane >> 5) * MF::KPL * (int)sizeof(TIN);
+
+    // ---- segment-0 halo pieces: this thread's piece j (0..4) of every chunk --------------------------------------------
+    int ppix[PIECE_ITERS], pdst[PIECE_ITERS]; unsigned pmask[PIECE_ITERS];
+#pragma unroll
+    for (int j = 0; j < PIECE_ITERS; ++j) {
+        const int idx = j * 512 + tid;
+        const int pix = idx / PARTS;
+        const int hy = pix / V4_HW, hx = pix - hy * V4_HW;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const bool inb = idx < NPIECE && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        ppix[j] = inb ? (b * p.H + gy) * p.W + gx : 0;
+        pmask[j] = inb ? 0xffffffffu : 0u;
+        pdst[j] = idx < NPIECE ? hy * HPITCH + hx * ROWB + part * 16 : -1;
+    }
+    const int dummy_off = MAIN_BYTES + tid * 16;
+    float ca[VEC], cb[VEC];                                  // GroupNorm affine of the chunk being staged
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { ca[k] = 1.f; cb[k] = 0.f; }
+    auto load_coef = [&](int chunk) {
+        if (p.coef) {
+            const float* cf = p.coef + ((size_t)b * Ctot + chunk * CK + part * VEC) * 2;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { ca[k] = cf[2 * k]; cb[k] = cf[2 * k + 1]; }
+        }
+    };
+    // buffer loads: tensor descriptor + uniform SGPR offset + 32-bit lane offset
+    auto buf_ld = [&](const void* base, unsigned voff, unsigned soff) -> uint4 {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    };
+    auto src_ld0 = [&](int chunk, int pixoff) -> uint4 {
+        const int c_glob = chunk * CK;
+        const TIN* src; int Cs, c_loc;
+        if (c_glob < p.C0) { src = (const TIN*)p.src0; Cs = p.C0; c_loc = c_glob; }
+        else               { src = (const TIN*)p.src1; Cs = p.C1; c_loc = c_glob - p.C0; }
+        const unsigned voff = (unsigned)pixoff * (unsigned)(Cs * (int)sizeof(TIN)) + (unsigned)(part * 16);
+        return buf_ld(src, voff, (unsigned)(c_loc * (int)sizeof(TIN)));
+    };
+    // ---- segment-1 (shortcut) pieces: the 16x32 centre pixels, 4 per thread, raw ----------------------------------------
+    auto load_piece1 = [&](int chunk2, int q, uint4& raw) -> unsigned {
+        const int pix = (q * 512 + tid) / PARTS;             // 0..511
+        const int gy = ty0 + (pix >> 5), gx = tx0 + (pix & 31);
+        const bool inb = gy < p.H && gx < p.W;
+        const int c_glob = chunk2 * CK;
+        const TIN* src; int Cs, c_loc;
+        if (c_glob < p.XC0) { src = (const TIN*)p.x0; Cs = p.XC0; c_loc = c_glob; }
+        else                { src = (const TIN*)p.x1; Cs = p.XC1; c_loc = c_glob - p.XC0; }
+        const unsigned pixoff = inb ? (unsigned)((b * p.H + gy) * p.W + gx) : 0u;
+        raw = buf_ld(src, pixoff * (unsigned)(Cs * (int)sizeof(TIN)) + (unsigned)(part * 16), (unsigned)(c_loc * (int)sizeof(TIN)));
+        return inb ? 0xffffffffu : 0u;
+    };
+    auto piece1_dst = [&](int q, int hb) -> int {
+        const int pix = (q * 512 + tid) / PARTS;
+        return hb * HALO_BYTES + ((pix >> 5) + 1) * HPITCH + ((pix & 31) + 1) * ROWB + part * 16;
+    };
+
+    // ---- weights: slab-major copy [tap][chunk][cout_pad][CK]; one 16-byte piece per thread per slab ----------------------
+    const unsigned wvoff = (unsigned)tid * 16u;
+    const int wdst = 2 * HALO_BYTES + (tid / PARTS) * ROWB + part * 16;
+    const unsigned slab_b = (unsigned)(p.cout_pad * CK) * (unsigned)sizeof(TIN);     // bytes per (tap, chunk) slab
+    const unsigned n0_b = (unsigned)(n0 * CK) * (unsigned)sizeof(TIN);
+    // weights of iteration (chunk CC, tap TT) -> R ; TT may run past 8 (wraps into the next chunk)
+#define V4_LOAD_W(CC, TT, R)                                                                                         \
+    {                                                                                                                \
+        const int cw_ = (TT) > 8 ? (CC) + 1 : (CC);                                                                  \
+        const int tw_ = (TT) > 8 ? (TT)-9 : (TT);                                                                    \
+        if (cw_ < nchunks) R = buf_ld(p.wb, wvoff, (unsigned)(tw_ * nchunks + cw_) * slab_b + n0_b);                 \
+    }
+#define V4_STORE_W(BUF, R) { *reinterpret_cast<uint4*>(smem + (BUF)*W_BYTES + wdst) = R; }
+
+    // ---- prologue: chunk 0 halo (synchronous), weights of iterations 0 and 1 -------------------------------------------
+    uint4 wa = make_uint4(0, 0, 0, 0);
+    {
+        uint4 w0 = wa, raw[PIECE_ITERS];
+        V4_LOAD_W(0, 0, w0);
+        V4_LOAD_W(0, 1, wa);                                 // stored by LDS(0)
+#pragma unroll
+        for (int j = 0; j < PIECE_ITERS; ++j) raw[j] = src_ld0(0, ppix[j]);
+        load_coef(0);
+        V4_STORE_W(0, w0);
+#pragma unroll
+        for (int j = 0; j < PIECE_ITERS; ++j)
+            *reinterpret_cast<uint4*>(smem + (pdst[j] >= 0 ? pdst[j] : dummy_off)) = v4_transform<TIN, ACT>(raw[j], pmask[j], ca, cb);
+    }
+
+    typename MF::frag af[KSTEPS][TM], bf[KSTEPS][TN];
+    uint4 hL = wa, hT = wa, t0 = wa;                         // piece in flight, piece being transformed, transformed piece
+    // Per (chunk CC, tap T), T a literal.  Piece k (0..4) of chunk CC+1: global load issued in LDS(k) -> parked in plain
+    // registers in LDS(k+1) -> GroupNorm+SiLU on the VALU behind the MFMAs of MFMA(k+1) -> written in LDS(k+2).
+#define V4_LDS(CC, T)                                                                                                \
+    {                                                                                                                \
+        const int cc_ = (CC);                                                                                        \
+        const int par_ = cc_ & 1;                            /* halo buffer this chunk reads; it parity = par_ ^ (T&1) */ \
+        const bool next_ = cc_ + 1 < nchunks;                                                                        \
+        {                                                                                                            \
+            const char* ha_ = smem + par_ * HALO_BYTES + ((T) / 3) * HPITCH + ((T) % 3) * ROWB;                      \
+            const char* wbuf_ = smem + (par_ ^ ((T)&1)) * W_BYTES;                                                   \
+            _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk) {                                                  \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) af[kk][i] = MF::ld(ha_ + a_base[i] + kk * KB);        \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[kk][j] = MF::ld(wbuf_ + b_base[j] + kk * KB);      \
+            }                                                                                                        \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if ((T) >= 2 && (T) < PIECE_ITERS + 2 && next_) {                                                            \
+            constexpr int k_ = (T) >= 2 && (T) < PIECE_ITERS + 2 ? (T)-2 : 0;                                        \
+            *reinterpret_cast<uint4*>(smem + (pdst[k_] >= 0 ? (par_ ^ 1) * HALO_BYTES + pdst[k_] : dummy_off)) = t0;  \
+        }                                                                                                            \
+        if ((T) < 8 || next_) V4_STORE_W((par_ ^ ((T)&1)) ^ 1, wa);                                                  \
+        if ((T) >= 1 && (T) < PIECE_ITERS + 1) {                                                                     \
+            /* the piece loaded one iteration ago has landed: park it in plain registers so that the MFMA-phase    */ \
+            /* transform carries no vmcnt wait on this phase's fresh loads                                          */ \
+            hT = hL;                                                                                                 \
+            asm volatile("" : "+v"(hT.x), "+v"(hT.y), "+v"(hT.z), "+v"(hT.w));                                       \
+        }                                                                                                            \
+        if ((T) < PIECE_ITERS && next_) {                                                                            \
+            if ((T) == 0) load_coef(cc_ + 1);                                                                        \
+            constexpr int k_ = (T) < PIECE_ITERS ? (T) : 0;                                                          \
+            hL = src_ld0(cc_ + 1, ppix[k_]);                                                                         \
+        }                                                                                                            \
+        V4_LOAD_W(cc_, (T) + 2, wa);                                                                                 \
+    }
+#define V4_MFMA(CC, T)                                                                                               \
+    {                                                                                                                \
+        _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk)                                                        \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                           \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);  \
+        if ((T) >= 1 && (T) < PIECE_ITERS + 1) {             /* unconditional at run time: same basic block as the MFMAs */ \
+            constexpr int k_ = (T) >= 1 && (T) < PIECE_ITERS + 1 ? (T)-1 : 0;                                        \
+            t0 = v4_transform<TIN, ACT>(hT, pmask[k_], ca, cb);                                                      \
+            asm volatile("" : "+v"(t0.x), "+v"(t0.y), "+v"(t0.z), "+v"(t0.w));   /* materialise here, not at the ds_write */ \
+            _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                         \
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * KSTEPS / 16, 0);   /* MFMA  */                 \
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                       /* 3 VALU  */               \
+                __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);                       /* 1 TRANS */               \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+
+    // Ping-pong over the 3x3 segment: the two waves that share a SIMD (w and w+4) are always in opposite phases.
+    //   phase:   0        1        2        3        4       ...
+    //   G0:    LDS(0)  MFMA(0)  LDS(1)  MFMA(1)  LDS(2)
+    //   G1:     --     LDS(0)  MFMA(0)  LDS(1)  MFMA(1)
+#define V4_BAR() { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
+    V4_STAMP(2)
+    V4_BAR();
+    V4_STAMP(3)
+    if (wave < 4) {
+        V4_LDS(0, 0)
+        V4_BAR();
+        for (int c = 0; c < nchunks; ++c) {
+#define V4_G0_STEP(T) V4_MFMA(c, T) V4_BAR(); V4_LDS(c, (T) + 1) V4_BAR();
+            V4_G0_STEP(0) V4_G0_STEP(1) V4_G0_STEP(2) V4_G0_STEP(3) V4_G0_STEP(4) V4_G0_STEP(5) V4_G0_STEP(6) V4_G0_STEP(7)
+#undef V4_G0_STEP
+            V4_MFMA(c, 8)
+            V4_BAR();
+            if (c + 1 < nchunks) V4_LDS(c + 1, 0)
+            V4_BAR();
+        }
+    } else {
+        V4_BAR();
+        for (int c = 0; c < nchunks; ++c) {
+#define V4_G1_STEP(T) V4_LDS(c, T) V4_BAR(); V4_MFMA(c, T) V4_BAR();
+            V4_G1_STEP(0) V4_G1_STEP(1) V4_G1_STEP(2) V4_G1_STEP(3) V4_G1_STEP(4) V4_G1_STEP(5) V4_G1_STEP(6) V4_G1_STEP(7) V4_G1_STEP(8)
+#undef V4_G1_STEP
+        }
+    }
+#undef V4_BAR
+#undef V4_LDS
+#undef V4_LOAD_W
+
+    V4_STAMP(4)
+    // ---- segment 1: the fused 1x1 shortcut: raw centre pixels; double-buffered, one barrier per iteration ---------------
+    if (nchunks2 > 0) {
+        uint4 r0, r1, r2, r3; unsigned m0, m1, m2, m3;
+        const unsigned slab2_b = (unsigned)(p.cout_pad * CK) * (unsigned)sizeof(TIN);
+#define V4_SC_LOAD(C2)                                                                                        \
+        {                                                                                                     \
+            m0 = load_piece1(C2, 0, r0); m1 = load_piece1(C2, 1, r1); m2 = load_piece1(C2, 2, r2); m3 = load_piece1(C2, 3, r3); \
+            wa = buf_ld(p.w2b, wvoff, (unsigned)(C2)*slab2_b + n0_b);                                         \
+        }
+        V4_SC_LOAD(0)
+        for (int c2 = 0; c2 < nchunks2; ++c2) {
+            const int buf = c2 & 1;
+            r0.x &= m0; r0.y &= m0; r0.z &= m0; r0.w &= m0; r1.x &= m1; r1.y &= m1; r1.z &= m1; r1.w &= m1;
+            r2.x &= m2; r2.y &= m2; r2.z &= m2; r2.w &= m2; r3.x &= m3; r3.y &= m3; r3.z &= m3; r3.w &= m3;
+            *reinterpret_cast<uint4*>(smem + piece1_dst(0, buf)) = r0; *reinterpret_cast<uint4*>(smem + piece1_dst(1, buf)) = r1;
+            *reinterpret_cast<uint4*>(smem + piece1_dst(2, buf)) = r2; *reinterpret_cast<uint4*>(smem + piece1_dst(3, buf)) = r3;
+            V4_STORE_W(buf, wa);
+            __syncthreads();
+            if (c2 + 1 < nchunks2) V4_SC_LOAD(c2 + 1)
+            const char* ha_ = smem + buf * HALO_BYTES + HPITCH + ROWB;        // centre tap
+            const char* wb2_ = smem + buf * W_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[kk][i] = MF::ld(ha_ + a_base[i] + kk * KB);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[kk][j] = MF::ld(wb2_ + b_base[j] + kk * KB);
+            }
+            V4_MFMA(nchunks, 0)
+        }
+#undef V4_SC_LOAD
+    }
+    V4_STAMP(5)
+    __syncthreads();                                         // the epilogue re-uses the LDS
+    V4_STAMP(6)
+#undef V4_MFMA
+#undef V4_STORE_W
+
+    // ------------------------------ epilogue: per-wave LDS transpose, 16-byte I/O ------------------------------------------
+    constexpr int STG_LD = BN + 4;
+    constexpr int STG_WAVE = 32 * STG_LD * 4;                // 16,896 B per wave and round
+    constexpr int CH = 16 / (int)sizeof(TOUT);
+    constexpr int CPR = BN / CH;                             // 16-byte chunks per pixel row: 16 (bf16) / 32 (fp32)
+    constexpr int QN = 32 * CPR / 64;                        // passes per round: 8 / 16
+    float* const stg = reinterpret_cast<float*>(smem + wave * STG_WAVE);
+    float* const red = reinterpret_cast<float*>(smem + 8 * STG_WAVE);     // [8 waves][BN][2]
+    TOUT* out = (TOUT*)p.out;
+    const TOUT* res = (const TOUT*)p.res;
+    const int ch = lane % CPR;
+    const int co0 = n0 + ch * CH;
+    const bool cok = co0 < p.Cout;
+    float st_s[CH], st_q[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { st_s[c] = 0.f; st_q[c] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int gy = ty0 + wave * 2 + i;                   // this round's tile row
+        // residual pieces of this round are fetched before the transposition (their latency overlaps it)
+        uint4 resv[QN];
+        if (res) {
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                const int gx = tx0 + (q * 64 + lane) / CPR;
+                const bool ok = cok && gy < p.H && gx < p.W;
+                const size_t pix = ok ? (size_t)(b * p.H + gy) * p.W + gx : 0;
+                resv[q] = *reinterpret_cast<const uint4*>(res + pix * p.Cout + (ok ? co0 : 0));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                stg[row * STG_LD + j * 32 + (lane & 31)] = acc[i][j][r] + addv[j];
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            const int row = (q * 64 + lane) / CPR;           // pixel column inside the tile row
+            const int gx = tx0 + row;
+            float v[CH];
+#pragma unroll
+            for (int c4 = 0; c4 < CH / 4; ++c4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(stg + row * STG_LD + ch * CH + c4 * 4);
+                v[c4 * 4] = t4.x; v[c4 * 4 + 1] = t4.y; v[c4 * 4 + 2] = t4.z; v[c4 * 4 + 3] = t4.w;
+            }
+            if (cok && gy < p.H && gx < p.W) {
+                const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+                if (res) {
+                    float rv[CH];
+                    Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&resv[q]), rv);
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) v[c] += rv[c];
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) v[c] *= p.out_scale;
+                if (p.pyr) {
+                    const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const float4 wq = *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4);
+                        v[c] += p.b4[co0 + c] + wq.x * pq.x + wq.y * pq.y + wq.z * pq.z + wq.w * pq.w;
+                    }
+                }
+                const uint4 packed = Vec16<TOUT>::pack(v);
+                *reinterpret_cast<uint4*>(out + pix * p.Cout + co0) = packed;
+                if (p.stats) {
+                    float vr[CH];
+                    Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&packed), vr);
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) { st_s[c] += vr[c]; st_q[c] += vr[c] * vr[c]; }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        V4_STAMP(7)
+    }
+    if (p.stats) {
+        // lanes holding the same 16-byte channel chunk are CPR apart inside a wave
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (CPR == 16) { st_s[c] = reduce_lanes_stride<16>(st_s[c]); st_q[c] = reduce_lanes_stride<16>(st_q[c]); }
+            else { st_s[c] += __shfl_xor(st_s[c], 32); st_q[c] += __shfl_xor(st_q[c], 32); }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                red[(wave * BN + ch * CH + c) * 2] = st_s[c]; red[(wave * BN + ch * CH + c) * 2 + 1] = st_q[c];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+            const int co = n0 + tid;
+            if (co < p.Cout) {
+                float* dst = p.stats + (((size_t)b * gridDim.x + tile) * p.Cout + co) * 2;
+                dst[0] = s; dst[1] = q;
+            }
+        }
+    }
+    V4_STAMP(8)
+}
+
+template <typename TIN, typename TOUT, int CK, bool ACT>
+static void v4_launch_t(const ConvArgs& a, hipStream_t s) {
+    constexpr int ROWB = CK * (int)sizeof(TIN) + 16;
+    constexpr int MAIN = 2 * V4_HH * V4_HW * ROWB + 2 * V4_BN * ROWB + 512 * 16;
+    constexpr int EPI = 8 * 32 * (V4_BN + 4) * 4 + 8 * V4_BN * 2 * 4;
+    constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
+    static bool attr_set = false;
+    auto kern = conv_v4_kernel<TIN, TOUT, CK, ACT>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr_set = true;
+    }
+    dim3 grid(conv_v4_tiles(a.H, a.W), (a.Cout + V4_BN - 1) / V4_BN, a.B);
+    hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, s, a);
+}
+
+static long g_v4_min_blocks = 128;
+void conv_v4_set_min_blocks(long n) { g_v4_min_blocks = n; }
+
+bool conv_v4_eligible(const ConvArgs& a) {
+    static const bool off = getenv("USE_HIP_NO_V4") != nullptr && atoi(getenv("USE_HIP_NO_V4")) != 0;   // A/B switch
+    const int Ctot = a.C0 + a.C1, XC = a.XC0 + a.XC1;
+    const int ck = conv_v4_chunk(a.in_dtype);
+    // 512-pixel tiles need enough workgroups per image to fill the chip evenly at batch 8; smaller maps stay on conv_v2
+    // (use_set_option("conv_v4_min_blocks", n) moves the threshold: the parity tests force the kernel onto small maps)
+    // (per image, so that the kernel choice - and with it the summation order - does not depend on the batch size)
+    const long blocks = (long)conv_v4_tiles(a.H, a.W) * ((a.Cout + V4_BN - 1) / V4_BN);
+    return !off && a.wb != nullptr && (XC == 0 || a.w2b != nullptr) && a.ntaps == 9 && a.Cout > 32 && a.in_dtype == a.out_dtype &&
+           Ctot % ck == 0 && XC % ck == 0 && a.cout_pad % V4_BN == 0 && a.H % V4_TH == 0 && a.W % V4_TW == 0 && blocks >= g_v4_min_blocks;
+}
+
+void launch_conv_v4(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+#ifdef USE_HIP_TRACE_BUILD
+    if (getenv("USE_HIP_TRACE")) {           // bring-up only: print the coarse timeline of the first H=512 launch with a given Cin
+        static int printed = 0;
+        static unsigned long long* trace_buf = nullptr;
+        if (!trace_buf) (void)hipMalloc((void**)&trace_buf, 512 * 8);
+        if (!printed && a.H == 512 && a.C0 + a.C1 == atoi(getenv("USE_HIP_TRACE")) && a.in_dtype == DT_BF16) {
+            (void)hipMemsetAsync(trace_buf, 0, 512 * 8, s);
+            a.trace = trace_buf;
+            a.act ? v4_launch_t<__bf16, __bf16, 32, true>(a, s) : v4_launch_t<__bf16, __bf16, 32, false>(a, s);
+            (void)hipStreamSynchronize(s);
+            unsigned long long hbuf[512];
+            (void)hipMemcpy(hbuf, trace_buf, sizeof hbuf, hipMemcpyDeviceToHost);
+            for (int g = 0; g < 2; ++g) {
+                unsigned long long prev = hbuf[g * 256 + 1];
+                for (int i = 0; i < 120 && hbuf[g * 256 + 2 * i]; ++i) {
+                    fprintf(stderr, "[trace v4 G%d] id %3llu  +%6llu\n", g, hbuf[g * 256 + 2 * i], hbuf[g * 256 + 2 * i + 1] - prev);
+                    prev = hbuf[g * 256 + 2 * i + 1];
+                }
+            }
+            printed = 1;
+            a.trace = nullptr;
+        }
+    }
+#endif
+    if (a.in_dtype == DT_BF16) { a.act ? v4_launch_t<__bf16, __bf16, 32, true>(a, s) : v4_launch_t<__bf16, __bf16, 32, false>(a, s); }
+    else                       { a.act ? v4_launch_t<float, float, 16, true>(a, s) : v4_launch_t<float, float, 16, false>(a, s); }
+}
+
+}  // namespace use

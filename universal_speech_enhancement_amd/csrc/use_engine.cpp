@@ -46,7 +46,8 @@ static inline uint16_t f32_to_bf16(float f) {   // round to nearest even
 // architecture description
 // ---------------------------------------------------------------------------------------------------------
 struct ConvW { std::string wname, bname; int cin = 0, cout = 0, cout_pad = 0, ntaps = 1, w_dtype = DT_F32;
-               bool nin = false; size_t w_off = 0, b_off = 0; };
+               bool nin = false; size_t w_off = 0, b_off = 0;
+               size_t wb_off = 0; bool has_wb = false; };     // slab-major copy for conv_v4_kernel (see pack_conv)
 struct GNW { std::string prefix; int C = 0; size_t g_off = 0, b_off = 0; };
 struct ResW { int idx = 0, in_ch = 0, out_ch = 0; bool up = false, down = false, has_c2 = false;
               GNW gn0, gn1; ConvW c0, c1, c2; int dense_row0 = 0; size_t b12_off = 0; };   // b12 = Conv_1.bias + Conv_2.bias
@@ -225,6 +226,9 @@ static int build_arch(use_handle* h) {
     auto lay_conv = [&](ConvW& w) {
         w.w_off = take((size_t)w.ntaps * w.cout_pad * w.cin * dtype_size(w.w_dtype));
         w.b_off = take((size_t)w.cout * 4);
+        // 3x3 convolutions and the res-block shortcuts fused into them get a second, slab-major copy
+        w.has_wb = !w.nin && w.cout_pad % 128 == 0 && w.cin % conv_v4_chunk(w.w_dtype) == 0 && (w.ntaps == 9 || w.ntaps == 1);
+        if (w.has_wb) w.wb_off = take((size_t)w.ntaps * w.cout_pad * w.cin * dtype_size(w.w_dtype));
     };
     auto lay_gn = [&](GNW& g) { g.g_off = take((size_t)g.C * 4); g.b_off = take((size_t)g.C * 4); };
     h->outw_off = take(8 * 4); h->outb_off = take(2 * 4);
@@ -261,6 +265,18 @@ static void pack_conv(const use_handle* h, const ConvW& w, char* blob) {
                 const size_t o = ((size_t)co * w.ntaps + tap) * w.cin + ci;   // [cout][tap][cin]: see use_kernels.h
                 if (w.w_dtype == DT_F32) ((float*)dst)[o] = v; else ((uint16_t*)dst)[o] = f32_to_bf16(v);
             }
+    if (w.has_wb) {                                           // [tap][chunk][cout_pad][ck]: one (tap, chunk) slab contiguous
+        const int ck = conv_v4_chunk(w.w_dtype), nchunks = w.cin / ck;
+        char* dstb = blob + w.wb_off;
+        memset(dstb, 0, (size_t)w.ntaps * w.cout_pad * w.cin * es);
+        for (int tap = 0; tap < w.ntaps; ++tap)
+            for (int co = 0; co < w.cout; ++co)
+                for (int ci = 0; ci < w.cin; ++ci) {
+                    const float v = src[((size_t)co * w.cin + ci) * w.ntaps + tap];
+                    const size_t o = (((size_t)tap * nchunks + ci / ck) * w.cout_pad + co) * ck + ci % ck;
+                    if (w.w_dtype == DT_F32) ((float*)dstb)[o] = v; else ((uint16_t*)dstb)[o] = f32_to_bf16(v);
+                }
+    }
     memcpy(blob + w.b_off, bias.data(), (size_t)w.cout * 4);
 }
 static void pack_gn(const use_handle* h, const GNW& g, char* blob) {
@@ -341,15 +357,17 @@ struct Fwd {
         ConvArgs p{};
         p.src0 = a.p; p.C0 = a.C; p.src1 = a2 ? a2->p : nullptr; p.C1 = a2 ? a2->C : 0; p.in_dtype = a.dtype;
         p.coef = coef; p.act = act; p.w = h->blob + w.w_off; p.cout_pad = w.cout_pad;
+        p.wb = w.has_wb ? h->blob + w.wb_off : nullptr;
         p.bias = W<float>(w2 ? bias_off : w.b_off);
-        if (w2) { p.x0 = sx0->p; p.XC0 = sx0->C; p.x1 = sx1 ? sx1->p : nullptr; p.XC1 = sx1 ? sx1->C : 0; p.w2 = h->blob + w2->w_off; }
+        if (w2) { p.x0 = sx0->p; p.XC0 = sx0->C; p.x1 = sx1 ? sx1->p : nullptr; p.XC1 = sx1 ? sx1->C : 0; p.w2 = h->blob + w2->w_off;
+                  p.w2b = w2->has_wb ? h->blob + w2->wb_off : nullptr; }
         p.temb = temb; p.temb_bstride = temb_bstride;
         p.res = res ? res->p : nullptr; p.out_scale = scale;
         p.pyr = pyr; p.w4 = cb ? W<float>(cb->w_off) : nullptr; p.b4 = cb ? W<float>(cb->b_off) : nullptr;
         p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
         p.B = h->B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
         o.ntiles = conv_out_tiles(p);
-        const bool main_variant = conv_v2_eligible(p);        // the dominant kernel: conv_v2_kernel launches only
+        const bool main_variant = conv_v2_eligible(p) || conv_v4_eligible(p);   // the dominant kernels (large maps) only
         if (h->profile && main_variant) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, s);
@@ -578,6 +596,11 @@ static int ensure_cap_stream(use_handle* h) {
 // ---------------------------------------------------------------------------------------------------------
 extern "C" {
 
+int use_set_option(const char* name, long long value) {
+    if (!name) return fail(USE_E_INVALID, "option name is null");
+    if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
+    return fail(USE_E_INVALID, "unknown option '%s'", name);
+}
 const char* use_last_error(void) { return g_err.c_str(); }
 const char* use_version(void) { return "use_hip 0.1 (gfx950)"; }
 

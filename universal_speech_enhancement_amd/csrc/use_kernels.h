@@ -24,13 +24,14 @@ struct ConvArgs {
     const void* src0; const void* src1; int C0; int C1; int in_dtype;
     const float* coef;      // [B][C0+C1][2] (a, b) or null
     int act;                // 0: none, 1: SiLU (after the affine)
-    const void* w;          // packed [CoutPad][ntaps][C0+C1] in in_dtype: the 128 rows of one (tap, chunk) slab lie
-                            // ntaps*Cin*2 bytes apart, i.e. on different pages / L2 channels (all CUs fetch the same slab
-                            // at about the same time)
+    const void* w;          // packed [CoutPad][ntaps][C0+C1] in in_dtype
+    const void* wb;         // optional slab-major copy [ntaps][(C0+C1)/ck][CoutPad][ck], ck = conv_v4_chunk(in_dtype)
+                            // (one (tap, chunk) slab contiguous: conv_v4_kernel), or null
     int cout_pad;
     // optional second K segment: + conv1x1(concat(x0[XC0], x1[XC1])) with weights w2 [CoutPad][1][XC0+XC1]
     // (the res-block shortcut Conv_2 fused into Conv_1; raw input, no affine / activation)
     const void* x0; const void* x1; int XC0; int XC1; const void* w2;
+    const void* w2b;        // slab-major copy of w2: [(XC0+XC1)/ck][CoutPad][ck], or null
     const float* bias;      // [Cout] or null
     const float* temb;      // [B or 1][temb_stride] slice start for this conv, or null
     int temb_bstride;       // elements between batch rows (0: shared by the batch)
@@ -50,8 +51,16 @@ void launch_conv(const ConvArgs& a, hipStream_t s);
 bool conv_v2_eligible(const ConvArgs& a);
 void launch_conv_v2(const ConvArgs& a, hipStream_t s);
 void launch_conv_v3(const ConvArgs& a, hipStream_t s);   // wave-specialised variant (use_conv_v3.hip), same tiles as v2
+// wide-tile variant (use_conv_v4.hip): 16x32-pixel tiles, K chunks of conv_v4_chunk() channels, slab-major weights
+inline int conv_v4_chunk(int dtype) { return dtype == DT_BF16 ? 32 : 16; }
+inline int conv_v4_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 31) / 32); }
+bool conv_v4_eligible(const ConvArgs& a);
+void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 128 workgroups per image)
+void launch_conv_v4(const ConvArgs& a, hipStream_t s);
 // number of per-image statistics tiles the kernel chosen for `a` writes (stats layout [B][tiles][Cout][2])
-inline int conv_out_tiles(const ConvArgs& a) { return conv_v2_eligible(a) ? conv_v2_tiles(a.H, a.W) : tiles_per_image(a.H, a.W); }
+inline int conv_out_tiles(const ConvArgs& a) {
+    return conv_v4_eligible(a) ? conv_v4_tiles(a.H, a.W) : conv_v2_eligible(a) ? conv_v2_tiles(a.H, a.W) : tiles_per_image(a.H, a.W);
+}
 
 // GroupNorm finalisation: per-(b, group) mean / rstd from per-tile per-channel partial sums of up to
 // two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b):  y = a*x + b.

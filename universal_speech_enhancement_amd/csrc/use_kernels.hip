@@ -306,6 +306,7 @@ static void conv_launch_t(const ConvArgs& a, hipStream_t s) {
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {
+    if (conv_v4_eligible(a)) { launch_conv_v4(a, s); return; }
     if (conv_v2_eligible(a)) { launch_conv_v2(a, s); return; }
     const int Ctot = a.C0 + a.C1;
     const bool small_n = a.Cout <= 32;

@@ -30,6 +30,11 @@ def _require_cuda_c64(name: str, t: torch.Tensor, shape=None) -> torch.Tensor:
     return t
 
 
+def set_option(name: str, value: int) -> None:
+    """Process-wide tuning knob of the library (``use_set_option``), e.g. ``conv_v4_min_blocks``."""
+    check(_lib.lib().use_set_option(name.encode(), int(value)), "use_set_option")
+
+
 class HipScoreEngine:
     """One handle per (process, device).  Not re-entrant."""
 
