@@ -157,7 +157,7 @@ def main():
     x = out
     tvec = torch.full((B,), 0.5, device=dev)
     eng.profile_score(x, Y, tvec)                                   # warm
-    conv_ms, conv_flops, conv_launches, total_ms = eng.profile_score(x, Y, tvec)
+    conv_ms, conv_flops, conv_bytes, conv_launches, total_ms = eng.profile_score(x, Y, tvec)
     peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_FP32_TFLOPS
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
     # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), which cannot be
@@ -165,15 +165,16 @@ def main():
     traffic, traffic_src = None, None
     if a.precision == "bf16" and (B, Tp) == (8, 640):
         import glob
-        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_conv_v2.json")))
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_conv_v4.json")))
         if pm:
             traffic = round(json.load(open(pm[-1]))["hbm_bytes_per_launch"])
             traffic_src = os.path.relpath(pm[-1], ROOT)
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_source": traffic_src,
-                "algorithmic_hbm_bytes_per_launch": round(7.98e6 * B * Tp / max(conv_launches, 1)),
-                "kernel": "use::conv_v2_kernel<%s> (implicit-GEMM 3x3 conv, both ACT variants)" % ("bf16,bf16,64" if a.precision == "bf16" else "f32,f32,32"),
+                "algorithmic_hbm_bytes_per_launch": round(conv_bytes / max(conv_launches, 1)),
+                "kernel": "use::conv_v4_kernel<%s> (wide-tile implicit-GEMM 3x3 conv of the large maps, both ACT variants)"
+                          % ("bf16,bf16,32" if a.precision == "bf16" else "f32,f32,16"),
                 "launches_per_score": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                 "algorithmic_gflop_per_launch": round(conv_flops / max(conv_launches, 1) / 1e9, 2),
                 "kernel_time_share_of_score": round(conv_ms / total_ms, 3),

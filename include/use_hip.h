@@ -102,11 +102,12 @@ int use_sde_corrector(use_handle* h, int corrector, float t, float snr, int B, c
                       const void* noise, uint64_t seed, void* x_out, void* x_mean, int64_t n, use_stream_t s);
 
 /* Introspection for tests / profiling */
-/* One eager score evaluation with a HIP-event pair around every launch of the dominant conv kernel
- * (activation-dtype 3x3 / 1x1 implicit GEMM): summed kernel time, their algorithmic FLOPs, launch count, and the
- * wall time of the whole evaluation on `stream`.  Synchronises the stream. */
+/* One eager score evaluation with a HIP-event pair around every launch of the dominant kernel (conv_v4_kernel, the
+ * wide-tile implicit-GEMM 3x3 convolution of the large feature maps): summed kernel time, their algorithmic FLOPs and
+ * algorithmic HBM bytes (every operand once), launch count, and the wall time of the whole evaluation on `stream`.
+ * Synchronises the stream. */
 int use_profile_score(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream,
-                      double* conv_ms, double* conv_flops, int* conv_launches, double* total_ms);
+                      double* conv_ms, double* conv_flops, double* conv_bytes, int* conv_launches, double* total_ms);
 /* timesteps of the sampler, torch.linspace(1, t_eps, N) float32 semantics (sampling/__init__.py:63); host only */
 int use_timesteps(int N, float t_eps, float* out);
 int use_debug_tensor(use_handle* h, const char* name, void** dev_ptr, int* dims4, int* dtype);

@@ -27,5 +27,5 @@ ms = e0.elapsed_time(e1) / iters
 print(f"[{prec}] B={B} T'={T}: {ms:.2f} ms / score  -> {eng.flops_per_score() / ms / 1e9:.1f} TFLOP/s, {B*T/ms*1e3:.0f} padded-frame*NFE/s, finite={torch.isfinite(torch.view_as_real(out)).all().item()}")
 if os.environ.get("USE_HIP_PROFILE_VERBOSE"):
     eng.profile_score(x, y, t)
-    ms, fl, n, tot = eng.profile_score(x, y, t)
+    ms, fl, by, n, tot = eng.profile_score(x, y, t)
     print(f"conv launches {n}: {ms:.2f} ms of {tot:.2f} ms total, {fl/ms/1e9:.1f} TFLOP/s")

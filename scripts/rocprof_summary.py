@@ -1,18 +1,19 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 rocpd SQLite result (``--kernel-trace --stats``) as a per-kernel table (top_kernels view)."""
-import sqlite3
-import sys
+"""Summarise `rocprofv3 --kernel-trace --stats --output-format csv` output (scripts/run_profile.sh) per kernel.
+usage: rocprof_summary.py <dir-with-*_kernel_stats.csv> [bench-json-line-file]"""
+import csv, glob, os, sys
 
-db, out = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else None)
-con = sqlite3.connect(db)
-rows = list(con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-lines = [f"{'calls':>8} {'total_ms':>12} {'avg_us':>10} {'pct':>7}  kernel"]
-for name, calls, tot, avg, pct in rows:
-    if len(name) > 150:
-        name = name[:147] + "..."
-    lines.append(f"{calls:8d} {tot / 1e3:12.3f} {avg:10.3f} {pct:7.3f}  {name}")
-text = "\n".join(lines) + "\n"
-if out:
-    open(out, "a").write(text)
-else:
-    print(text)
+d = sys.argv[1]
+f = sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True))[0]
+rows = list(csv.DictReader(open(f)))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print(f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline` ({os.path.basename(f)})")
+print(f"# total kernel time {tot / 1e6:.2f} ms over {sum(int(r['Calls']) for r in rows)} launches")
+print(f"{'total ms':>10} {'%':>6} {'calls':>7} {'avg us':>9} {'min us':>8} {'max us':>8}  kernel")
+for r in rows[:24]:
+    print(f"{float(r['TotalDurationNs']) / 1e6:10.2f} {float(r['Percentage']):6.2f} {r['Calls']:>7} {float(r['AverageNs']) / 1e3:9.1f} "
+          f"{float(r['MinNs']) / 1e3:8.1f} {float(r['MaxNs']) / 1e3:8.1f}  {r['Name'][:110]}")
+if len(sys.argv) > 2 and os.path.exists(sys.argv[2]):
+    for line in open(sys.argv[2]):
+        if line.startswith('{"metric'):
+            print("# bench line of the profiled run:", line.strip()[:600])

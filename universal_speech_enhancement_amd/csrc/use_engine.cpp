@@ -112,7 +112,7 @@ struct use_handle {
     char* sde_buf = nullptr; unsigned long long* sde_rng = nullptr; float* sde_step = nullptr; float* sde_partial = nullptr;
     static constexpr int SDE_MAX_B = 1024, SDE_BLOCKS = 128;
     // per-launch HIP-event profiling of the dominant conv kernel (use_profile_score)
-    bool profile = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_flops;
+    bool profile = false, profile_all = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_flops, prof_bytes; std::vector<char> prof_main;
     std::vector<std::string> prof_desc;
     // introspection
     bool dry = false;
@@ -367,14 +367,21 @@ struct Fwd {
         p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
         p.B = h->B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
         o.ntiles = conv_out_tiles(p);
-        const bool main_variant = conv_v2_eligible(p) || conv_v4_eligible(p);   // the dominant kernels (large maps) only
-        if (h->profile && main_variant) {
+        const bool main_variant = conv_v4_eligible(p);        // the dominant kernel (conv_v4_kernel, large maps)
+        if (h->profile && (main_variant || (h->profile_all && conv_v2_eligible(p)))) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, s);
             launch_conv(p, s);
             (void)hipEventRecord(e1, s);
             h->prof_events.push_back({e0, e1});
-            h->prof_flops.push_back(fl);
+            h->prof_flops.push_back(fl); h->prof_main.push_back(main_variant);
+            {   // algorithmic HBM bytes of this launch: every operand once (input, shortcut input, residual, output, weights)
+                const double es = (double)dtype_size(a.dtype), px = (double)h->B * a.H * a.W;
+                double by = px * (w.cin + (w2 ? w2->cin : 0)) * es + px * w.cout * dtype_size(out_dtype) * (res ? 2.0 : 1.0);
+                by += (double)w.ntaps * w.cin * w.cout * es + (w2 ? (double)w2->cin * w2->cout * es : 0.0);
+                if (pyr) by += px * 4 * 4;
+                h->prof_bytes.push_back(by);
+            }
             char d[160]; snprintf(d, sizeof d, "%-28s H=%3d W=%3d Cin=%3d Cout=%3d taps=%d gn=%d res=%d sc=%d", w.wname.c_str(), a.H, a.W, w.cin, w.cout, w.ntaps, coef != nullptr, res != nullptr, w2 ? w2->cin : 0);
             h->prof_desc.push_back(d);
         } else {
@@ -756,22 +763,23 @@ int use_score(use_handle* h, const void* x, const void* y, const float* t, void*
 }
 
 int use_profile_score(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream,
-                      double* conv_ms, double* conv_flops, int* conv_launches, double* total_ms) {
+                      double* conv_ms, double* conv_flops, double* conv_bytes, int* conv_launches, double* total_ms) {
     int rc = check_ready(h); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t t0, t1; HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
-    h->profile = true; h->prof_events.clear(); h->prof_flops.clear(); h->prof_desc.clear();
+    h->profile = true; h->prof_events.clear(); h->prof_flops.clear(); h->prof_bytes.clear(); h->prof_desc.clear(); h->prof_main.clear();
     const bool verbose = getenv("USE_HIP_PROFILE_VERBOSE") != nullptr;
+    h->profile_all = verbose;                                 // verbose: also list the conv_v2_kernel launches
     HIPCHK(hipEventRecord(t0, s));
     rc = use_score(h, x, y, t, out, stream);
     h->profile = false;
     if (rc) return rc;
     HIPCHK(hipEventRecord(t1, s));
     HIPCHK(hipStreamSynchronize(s));
-    double ms = 0.0, fl = 0.0;
+    double ms = 0.0, fl = 0.0, by = 0.0; int nmain = 0;
     for (size_t i = 0; i < h->prof_events.size(); ++i) {
         float e = 0.f; HIPCHK(hipEventElapsedTime(&e, h->prof_events[i].first, h->prof_events[i].second));
-        ms += e; fl += h->prof_flops[i];
+        if (h->prof_main[i]) { ms += e; fl += h->prof_flops[i]; by += h->prof_bytes[i]; ++nmain; }
         if (verbose) fprintf(stderr, "[use_profile] %s  %8.3f ms  %7.1f TFLOP/s\n", h->prof_desc[i].c_str(), e, h->prof_flops[i] / e / 1e9);
         (void)hipEventDestroy(h->prof_events[i].first); (void)hipEventDestroy(h->prof_events[i].second);
     }
@@ -779,9 +787,11 @@ int use_profile_score(use_handle* h, const void* x, const void* y, const float* 
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     if (conv_ms) *conv_ms = ms;
     if (conv_flops) *conv_flops = fl;
-    if (conv_launches) *conv_launches = (int)h->prof_events.size();
+    if (conv_bytes) *conv_bytes = by;
+    if (conv_launches) *conv_launches = nmain;
     if (total_ms) *total_ms = tot;
-    h->prof_events.clear(); h->prof_flops.clear();
+    h->profile_all = false;
+    h->prof_events.clear(); h->prof_flops.clear(); h->prof_bytes.clear(); h->prof_main.clear();
     return USE_OK;
 }
 

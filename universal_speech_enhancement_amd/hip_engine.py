@@ -143,15 +143,16 @@ class HipScoreEngine:
         return out
 
     def profile_score(self, x, y, t):
-        """(conv_ms, conv_flops, conv_launches, total_ms) of one eager score evaluation (HIP events per launch)."""
+        """(conv_ms, conv_flops, conv_bytes, conv_launches, total_ms) of one eager score evaluation: HIP events around every
+        launch of the dominant kernel (conv_v4_kernel), its algorithmic FLOPs / HBM bytes, and the evaluation's wall time."""
         x = _require_cuda_c64("x", x); y = _require_cuda_c64("y", y, x.shape)
         self.plan(x.shape[0], x.shape[3])
         t = t.to(device=x.device, dtype=torch.float32).contiguous()
         out = torch.empty_like(x)
-        ms, fl, n, tot = C.c_double(), C.c_double(), C.c_int(), C.c_double()
+        ms, fl, by, n, tot = C.c_double(), C.c_double(), C.c_double(), C.c_int(), C.c_double()
         check(self.L.use_profile_score(self.h, x.data_ptr(), y.data_ptr(), t.data_ptr(), out.data_ptr(), _stream_ptr(x.device),
-                                       C.byref(ms), C.byref(fl), C.byref(n), C.byref(tot)), "use_profile_score")
-        return ms.value, fl.value, n.value, tot.value
+                                       C.byref(ms), C.byref(fl), C.byref(by), C.byref(n), C.byref(tot)), "use_profile_score")
+        return ms.value, fl.value, by.value, n.value, tot.value
 
     def set_sampler(self, N, predictor="reverse_diffusion", corrector="none", corrector_steps=1, snr=0.5, t_eps=3e-2,
                     use_graph=True):
