@@ -299,6 +299,240 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// pyr_conv_kernel: the output-pyramid convolutions (GroupNorm + SiLU -> 3x3 conv to 4 channels, + the up-sampled
+// pyramid so far; reference ncsnpp.py:437-470).  N = 4 is too narrow for conv_kernel's tiling (18 barrier-separated
+// steps of 4 MFMAs); the layer is bound by reading its input once.  One workgroup per 8x16-pixel tile: the normalised,
+// activated halo of 128 input channels (51 KB) and the 4 weight rows of all 9 taps are staged once per 128-channel block,
+// then each wave runs 72 MFMAs (32 pixels x [4 of 32] channels x K = 9 x 128) with no barrier in between.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PYR_CB = 128;                                  // input channels per staged block
+constexpr int PYR_ROWB = PYR_CB * 2 + 16;                    // 272: pixel row pitch in LDS
+constexpr int PYR_HPITCH = ((TILE_W + 2) * PYR_ROWB + 255) / 256 * 256;      // halo row pitch: multiple of 256 B (see conv_v2)
+constexpr int PYR_HALO = (TILE_H + 2) * PYR_HPITCH;
+constexpr int PYR_WB = 9 * 4 * PYR_ROWB;
+constexpr int PYR_SMEM = PYR_HALO + PYR_WB;
+__global__ __launch_bounds__(256) void pyr_conv_kernel(ConvArgs p) {
+    typedef Mfma<__bf16> MF;
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    char* const s_halo = psm;
+    char* const s_w = psm + PYR_HALO;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
+    const int ty0 = (blockIdx.x / tiles_x) * TILE_H, tx0 = (blockIdx.x % tiles_x) * TILE_W;
+    const int Cin = p.C0;
+    const __bf16* src = (const __bf16*)p.src0;
+    const int part = tid & 15;                               // this thread's 8 channels of every 128-channel block
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int m = lane & 31;
+    const int a_base = (wave * 2 + (m >> 4)) * PYR_HPITCH + (m & 15) * PYR_ROWB + (lane >> 5) * 16;
+    const int b_base = (lane & 3) * PYR_ROWB + (lane >> 5) * 16;           // output channels >= 4 are never stored
+    constexpr int NP = ((TILE_H + 2) * (TILE_W + 2) * 16 + 255) / 256;      // 12 halo pieces per thread
+    for (int c0 = 0; c0 < Cin; c0 += PYR_CB) {
+        if (c0) __syncthreads();                             // every wave is done with the previous block
+        float ca[8], cb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ca[k] = 1.f; cb[k] = 0.f; }
+        if (p.coef) {
+            const float* cf = p.coef + ((size_t)b * Cin + c0 + part * 8) * 2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ca[k] = cf[2 * k]; cb[k] = cf[2 * k + 1]; }
+        }
+        uint4 raw[NP]; int dst[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int idx = j * 256 + tid, pix = idx >> 4;
+            const int hy = pix / (TILE_W + 2), hx = pix - hy * (TILE_W + 2);
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const bool have = pix < (TILE_H + 2) * (TILE_W + 2);
+            const bool inb = have && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            dst[j] = have ? (inb ? 1 : 2) * 0x100000 + hy * PYR_HPITCH + hx * PYR_ROWB + part * 16 : 0;
+            raw[j] = inb ? *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.H + gy) * p.W + gx) * Cin + c0 + part * 8)
+                         : make_uint4(0, 0, 0, 0);
+        }
+        for (int i = tid; i < 9 * 4 * 16; i += 256) {        // weight rows 0..3: packed [CoutPad][9][Cin]
+            const int pc = i & 15, row = i >> 4;             // row = tap * 4 + co
+            const int tap = row >> 2, co = row & 3;
+            *reinterpret_cast<uint4*>(s_w + row * PYR_ROWB + pc * 16) =
+                *reinterpret_cast<const uint4*>((const __bf16*)p.w + ((size_t)co * 9 + tap) * Cin + c0 + pc * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            if (!dst[j]) continue;
+            uint4 o = make_uint4(0, 0, 0, 0);                // outside the image: the conv's zero padding
+            if (dst[j] < 0x200000) {
+                float v[8];
+                Vec16<__bf16>::load(reinterpret_cast<const __bf16*>(&raw[j]), v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { v[k] = fmaf(v[k], ca[k], cb[k]); if (p.act) v[k] = silu_f<false>(v[k]); }
+                o = Vec16<__bf16>::pack(v);
+            }
+            *reinterpret_cast<uint4*>(s_halo + (dst[j] & 0xfffff)) = o;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const char* ha = s_halo + a_base + (tap / 3) * PYR_HPITCH + (tap % 3) * PYR_ROWB;
+            const char* wb = s_w + b_base + tap * 4 * PYR_ROWB;
+#pragma unroll
+            for (int kk = 0; kk < PYR_CB / 16; ++kk) acc = MF::mma(MF::ld(ha + kk * 32), MF::ld(wb + kk * 32), acc);
+        }
+    }
+    __syncthreads();
+    float* const s_out = reinterpret_cast<float*>(psm);      // [128 pixels][4]
+    if ((lane & 31) < 4) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            s_out[(wave * 32 + row) * 4 + (lane & 31)] = acc[r];
+        }
+    }
+    __syncthreads();
+    if (tid < TILE_H * TILE_W) {
+        const int gy = ty0 + (tid >> 4), gx = tx0 + (tid & 15);
+        if (gy < p.H && gx < p.W) {
+            const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+            float4 v = *reinterpret_cast<const float4*>(s_out + tid * 4);
+            float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < p.Cout && p.bias) o[c] += p.bias[c];
+            if (p.res) {
+                const float* rp = (const float*)p.res + pix * p.Cout;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < p.Cout) o[c] += rp[c];
+            }
+            float* op = (float*)p.out + pix * p.Cout;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < p.Cout) op[c] = o[c] * p.out_scale;
+        }
+    }
+}
+static bool pyr_conv_eligible(const ConvArgs& a) {
+    return a.in_dtype == DT_BF16 && a.out_dtype == DT_F32 && a.ntaps == 9 && a.Cout <= 4 && a.C1 == 0 && a.C0 % PYR_CB == 0 &&
+           !a.temb && !a.pyr && !a.stats && a.XC0 + a.XC1 == 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_in_kernel: the network's first convolution (4 fp32 input channels -> Cout, 3x3, reference ncsnpp.py:326-331).
+// K = 36 is too shallow for the MFMA pipeline of conv_kernel (nine 4-deep chunks, a barrier each); the layer is bound by
+// writing its output, so it is a direct fp32 convolution on the VALU: one workgroup per 8x16-pixel tile x 128 output
+// channels, thread = (8-channel group, pixel column) x 8 rows, weights of one tap at a time in registers.
+// Output rounding, per-tile GroupNorm statistics and their layout are those of conv_kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <typename TOUT>
+__global__ __launch_bounds__(256) void conv_in_kernel(ConvArgs p) {
+    constexpr int CH = 8;                                    // output channels per thread
+    __shared__ __attribute__((aligned(16))) float s_in[(TILE_H + 2) * (TILE_W + 2) * 4];
+    __shared__ __attribute__((aligned(16))) float s_w[9 * 4 * 128];          // [tap][ci][co]
+    __shared__ float s_red[4 * 128 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = tid & 15, pl = tid >> 4;                  // channel group, pixel column
+    const int b = blockIdx.z;
+    const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
+    const int ty0 = (blockIdx.x / tiles_x) * TILE_H, tx0 = (blockIdx.x % tiles_x) * TILE_W;
+    const int n0 = blockIdx.y * 128;
+    const float* src = (const float*)p.src0;
+    for (int i = tid; i < (TILE_H + 2) * (TILE_W + 2); i += 256) {
+        const int hy = i / (TILE_W + 2), hx = i - hy * (TILE_W + 2);
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = *reinterpret_cast<const float4*>(src + ((size_t)(b * p.H + gy) * p.W + gx) * 4);
+        *reinterpret_cast<float4*>(s_in + i * 4) = v;
+    }
+    const float* wsrc = (const float*)p.w;                   // [CoutPad][9][4]
+    for (int i = tid; i < 128 * 9; i += 256) {
+        const int co = i / 9, tap = i - co * 9;
+        const float4 w4 = n0 + co < p.cout_pad ? *reinterpret_cast<const float4*>(wsrc + ((size_t)(n0 + co) * 9 + tap) * 4)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        s_w[(tap * 4 + 0) * 128 + co] = w4.x; s_w[(tap * 4 + 1) * 128 + co] = w4.y;
+        s_w[(tap * 4 + 2) * 128 + co] = w4.z; s_w[(tap * 4 + 3) * 128 + co] = w4.w;
+    }
+    __syncthreads();
+    float acc[TILE_H][CH];
+#pragma unroll
+    for (int r = 0; r < TILE_H; ++r)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[r][c] = 0.f;
+#pragma unroll 1                                             // one tap's 32 weights in registers at a time
+    for (int tap = 0; tap < 9; ++tap) {
+        float w[4][CH];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+            const float4 a = *reinterpret_cast<const float4*>(s_w + (tap * 4 + ci) * 128 + cg * CH);
+            const float4 c4 = *reinterpret_cast<const float4*>(s_w + (tap * 4 + ci) * 128 + cg * CH + 4);
+            w[ci][0] = a.x; w[ci][1] = a.y; w[ci][2] = a.z; w[ci][3] = a.w;
+            w[ci][4] = c4.x; w[ci][5] = c4.y; w[ci][6] = c4.z; w[ci][7] = c4.w;
+        }
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int r = 0; r < TILE_H; ++r) {
+            const float4 x = *reinterpret_cast<const float4*>(s_in + ((r + dy) * (TILE_W + 2) + pl + dx) * 4);
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                acc[r][c] = fmaf(x.x, w[0][c], fmaf(x.y, w[1][c], fmaf(x.z, w[2][c], fmaf(x.w, w[3][c], acc[r][c]))));
+        }
+    }
+    const int co0 = n0 + cg * CH;
+    const bool cok = co0 < p.Cout;
+    float bias[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) bias[c] = (cok && p.bias) ? p.bias[co0 + c] : 0.f;
+    float st_s[CH], st_q[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { st_s[c] = 0.f; st_q[c] = 0.f; }
+    TOUT* out = (TOUT*)p.out;
+    const int gx = tx0 + pl;
+#pragma unroll
+    for (int r = 0; r < TILE_H; ++r) {
+        const int gy = ty0 + r;
+        if (!cok || gy >= p.H || gx >= p.W) continue;
+        float v[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) v[c] = (acc[r][c] + bias[c]) * p.out_scale;
+        TOUT* dst = out + ((size_t)(b * p.H + gy) * p.W + gx) * p.Cout + co0;
+        float vr[CH];
+        if (sizeof(TOUT) == 2) {
+            const uint4 packed = Vec16<__bf16>::pack(v);
+            *reinterpret_cast<uint4*>(dst) = packed;
+            Vec16<__bf16>::load(reinterpret_cast<const __bf16*>(&packed), vr);
+        } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) vr[c] = v[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { st_s[c] += vr[c]; st_q[c] += vr[c] * vr[c]; }
+    }
+    if (p.stats) {
+        // lanes of a wave that hold the same channel group are 16 apart (4 pixel columns per wave)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { st_s[c] = reduce_lanes_stride<16>(st_s[c]); st_q[c] = reduce_lanes_stride<16>(st_q[c]); }
+        if (lane < 16) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { s_red[(wave * 128 + cg * CH + c) * 2] = st_s[c]; s_red[(wave * 128 + cg * CH + c) * 2 + 1] = st_q[c]; }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float sm = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { sm += s_red[(w * 128 + tid) * 2]; q += s_red[(w * 128 + tid) * 2 + 1]; }
+            const int co = n0 + tid;
+            if (co < p.Cout) {
+                float* dst = p.stats + (((size_t)b * gridDim.x + blockIdx.x) * p.Cout + co) * 2;
+                dst[0] = sm; dst[1] = q;
+            }
+        }
+    }
+}
+static bool conv_in_eligible(const ConvArgs& a) {
+    return a.in_dtype == DT_F32 && a.C0 == 4 && a.C1 == 0 && a.ntaps == 9 && !a.coef && !a.act && !a.res && !a.pyr && !a.temb &&
+           a.XC0 + a.XC1 == 0 && a.Cout % 8 == 0;
+}
+
 template <typename TIN, typename TOUT, int CK, int BN, int WM, int WN>
 static void conv_launch_t(const ConvArgs& a, hipStream_t s) {
     dim3 grid(tiles_per_image(a.H, a.W), (a.Cout + BN - 1) / BN, a.B);
@@ -308,6 +542,21 @@ static void conv_launch_t(const ConvArgs& a, hipStream_t s) {
 void launch_conv(const ConvArgs& a, hipStream_t s) {
     if (conv_v4_eligible(a)) { launch_conv_v4(a, s); return; }
     if (conv_v2_eligible(a)) { launch_conv_v2(a, s); return; }
+    if (pyr_conv_eligible(a)) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PYR_SMEM);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(pyr_conv_kernel, dim3(tiles_per_image(a.H, a.W), 1, a.B), dim3(256), PYR_SMEM, s, a);
+        return;
+    }
+    if (conv_in_eligible(a)) {
+        dim3 grid(tiles_per_image(a.H, a.W), (a.Cout + 127) / 128, a.B);
+        if (a.out_dtype == DT_BF16) hipLaunchKernelGGL((conv_in_kernel<__bf16>), grid, dim3(256), 0, s, a);
+        else                        hipLaunchKernelGGL((conv_in_kernel<float>), grid, dim3(256), 0, s, a);
+        return;
+    }
     const int Ctot = a.C0 + a.C1;
     const bool small_n = a.Cout <= 32;
     if (a.in_dtype == DT_BF16) {
@@ -497,6 +746,98 @@ __global__ __launch_bounds__(256) void fir_up_blk_kernel(const T* __restrict__ s
     }
 }
 
+// Down x2, one thread per 2x2 OUTPUT block (8 or 4 channels): the block reads a 6x6 input neighbourhood, each input is
+// loaded and normalised + activated once per thread (36 per 4 outputs instead of 64), and the separable [1,3,3,1]/8
+// kernel is applied horizontally per input row, then vertically.
+template <typename T>
+__global__ __launch_bounds__(256) void fir_down_blk_kernel(const T* __restrict__ src, const float* __restrict__ coef,
+                                                           int act, T* __restrict__ out_act, T* __restrict__ out_raw,
+                                                           int B, int H, int W, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    constexpr bool ACC = sizeof(T) == 4;
+    const int cv = C / VEC;
+    const int OH = H / 2, OW = W / 2, BH = (OH + 1) / 2, BW = (OW + 1) / 2;
+    const long total = (long)B * BH * BW * cv;
+    const bool want_act = out_act != nullptr;
+    const float k4[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * VEC;
+        long q = idx / cv;
+        const int bx = (int)(q % BW); q /= BW;
+        const int by = (int)(q % BH);
+        const int b = (int)(q / BH);
+        float ca[VEC], cb[VEC];
+        if (want_act && coef) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { ca[k] = coef[((size_t)b * C + c + k) * 2]; cb[k] = coef[((size_t)b * C + c + k) * 2 + 1]; }
+        }
+        float ar[2][2][VEC], aa[2][2][VEC];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) { ar[i][j][k] = 0.f; aa[i][j][k] = 0.f; }
+        const int y0 = 4 * by - 1, x0 = 4 * bx - 1;          // first input row / column of the 6x6 neighbourhood
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int y = y0 + r;
+            if (y < 0 || y >= H) continue;
+            float hr[2][VEC], ha[2][VEC];                    // horizontal pass of this input row for the two output columns
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) { hr[j][k] = 0.f; ha[j][k] = 0.f; }
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const int x = x0 + e;
+                if (x < 0 || x >= W) continue;
+                float v[VEC], u[VEC];
+                Vec16<T>::load(src + ((size_t)(b * H + y) * W + x) * C + c, v);
+                if (want_act) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        u[k] = coef ? fmaf(v[k], ca[k], cb[k]) : v[k];
+                        if (act) u[k] = silu_f<ACC>(u[k]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int t = e - 2 * j;                 // tap index of this input column for output column j
+                    if (t < 0 || t > 3) continue;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        hr[j][k] = fmaf(k4[t], v[k], hr[j][k]);
+                        if (want_act) ha[j][k] = fmaf(k4[t], u[k], ha[j][k]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int t = r - 2 * i;
+                if (t < 0 || t > 3) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        ar[i][j][k] = fmaf(k4[t], hr[j][k], ar[i][j][k]);
+                        if (want_act) aa[i][j][k] = fmaf(k4[t], ha[j][k], aa[i][j][k]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int oy = 2 * by + i, ox = 2 * bx + j;
+                if (oy >= OH || ox >= OW) continue;
+                const size_t o = ((size_t)(b * OH + oy) * OW + ox) * C + c;
+                if (out_raw) Vec16<T>::store(out_raw + o, ar[i][j]);
+                if (want_act) Vec16<T>::store(out_act + o, aa[i][j]);
+            }
+    }
+}
+
 template <bool UP>
 static void fir_launch(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
                        int H, int W, int C, hipStream_t s) {
@@ -514,15 +855,15 @@ static void fir_launch(const void* src, int dtype, const float* coef, int act, v
                                (__bf16*)out_act, (__bf16*)out_raw, B, H, W, C);
     } else {   // (an LDS-tiled variant that activates each input once measured slower: 64-byte input segments, 32 LDS reads/thread)
         const int OH = H / 2, OW = W / 2;
-        const long total = (long)B * OH * OW * (C / vec);
+        const long total = (long)B * ((OH + 1) / 2) * ((OW + 1) / 2) * (C / vec);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 256 * 16) blocks = 256 * 16;
         if (blocks < 1) blocks = 1;
         if (dtype == DT_F32)
-            hipLaunchKernelGGL((fir_kernel<float, false>), dim3(blocks), dim3(256), 0, s, (const float*)src, coef, act,
+            hipLaunchKernelGGL((fir_down_blk_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)src, coef, act,
                                (float*)out_act, (float*)out_raw, B, H, W, C);
         else
-            hipLaunchKernelGGL((fir_kernel<__bf16, false>), dim3(blocks), dim3(256), 0, s, (const __bf16*)src, coef, act,
+            hipLaunchKernelGGL((fir_down_blk_kernel<__bf16>), dim3(blocks), dim3(256), 0, s, (const __bf16*)src, coef, act,
                                (__bf16*)out_act, (__bf16*)out_raw, B, H, W, C);
     }
 }
