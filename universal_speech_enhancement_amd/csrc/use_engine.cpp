@@ -106,6 +106,13 @@ struct use_handle {
     float* ts_dev = nullptr; float* temb_table = nullptr; float* silu_table = nullptr;
     float2* noise_copy = nullptr; size_t noise_copy_bytes = 0;
     hipStream_t cap_stream = nullptr;
+    // sub-batch pipelining (see run_score): the batch is evaluated as two halves on two streams, the second started when
+    // the first reaches its small feature maps, so that one half's latency-bound kernels hide behind the other's large ones
+    int B0 = 0, B1 = 0;                          // sub-batch sizes (B1 = 0: not split)
+    Arena arena1;                                // workspace of the second sub-batch (inside the same allocation)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_stagger = nullptr, ev_join = nullptr;
+    int debug_B = 0;
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // [0]: device RNG, [1]: injected noise
     hipGraphExec_t score_graph = nullptr;
     // scratch for the stand-alone use_sde_* entry points (independent of weights / plan)
@@ -323,26 +330,32 @@ static int pack_all(use_handle* h, char* blob) {
 // ---------------------------------------------------------------------------------------------------------
 // forward pass (one score-network evaluation)
 // ---------------------------------------------------------------------------------------------------------
+static bool g_subbatch = true;                   // use_set_option("subbatch", 0/1)
+
 struct Fwd {
     use_handle* h; hipStream_t s;
-    const float* tembias; int temb_bstride;      // [B or 1][dense_rows]
+    const float* tembias; int temb_bstride;      // [B or 1][dense_rows] (already offset to this sub-batch)
     const float* t; int t_stride;                 // per-item time (stride 0: shared)
+    int B = 0;                                    // items of this (sub-)batch
+    Arena* arena = nullptr;                       // its activation workspace
+    bool primary = true;                          // the first sub-batch owns the FLOP count and the debug tensors
+    hipEvent_t ev_stagger = nullptr;              // recorded when the large maps of the down path are done (or null)
     template <typename T> const T* W(size_t off) const { return (const T*)(h->blob + off); }
 
     Act new_act(int C, int H, int Wd, int dtype, bool stats) {
         Act a; a.C = C; a.H = H; a.W = Wd; a.dtype = dtype;
-        a.p = h->arena.alloc((size_t)h->B * H * Wd * C * dtype_size(dtype));
-        if (stats) a.stats = (float*)h->arena.alloc((size_t)h->B * tiles_per_image(H, Wd) * C * 2 * 4);
+        a.p = arena->alloc((size_t)B * H * Wd * C * dtype_size(dtype));
+        if (stats) a.stats = (float*)arena->alloc((size_t)B * tiles_per_image(H, Wd) * C * 2 * 4);
         return a;
     }
 
     float* gn_coef(const Act& a, const Act* a2, const GNW& g) {
         const int C = a.C + (a2 ? a2->C : 0);
-        float* coef = (float*)h->arena.alloc((size_t)h->B * C * 2 * 4);
+        float* coef = (float*)arena->alloc((size_t)B * C * 2 * 4);
         if (!h->dry)
             launch_gn_finalize(a.stats, a.C, a.ntiles, a2 ? a2->stats : nullptr, a2 ? a2->C : 0, a2 ? a2->ntiles : 0,
                                W<float>(g.g_off), W<float>(g.b_off), std::min(C / 4, 32), a.H * a.W, 1e-6f, coef,
-                               h->B, s);
+                               B, s);
         return coef;
     }
 
@@ -350,8 +363,8 @@ struct Fwd {
              const Act* res, float scale, const float* pyr, const CombineW* cb, int out_dtype, bool stats,
              const Act* sx0 = nullptr, const Act* sx1 = nullptr, const ConvW* w2 = nullptr, size_t bias_off = 0) {
         Act o = new_act(w.cout, a.H, a.W, out_dtype, stats);
-        double fl = 2.0 * h->B * a.H * a.W * (double)w.cout * w.cin * w.ntaps;
-        if (w2) fl += 2.0 * h->B * a.H * a.W * (double)w2->cout * w2->cin;
+        double fl = 2.0 * B * a.H * a.W * (double)w.cout * w.cin * w.ntaps;
+        if (w2) fl += 2.0 * B * a.H * a.W * (double)w2->cout * w2->cin;
         h->flops += fl;
         if (h->dry) return o;
         ConvArgs p{};
@@ -365,7 +378,7 @@ struct Fwd {
         p.res = res ? res->p : nullptr; p.out_scale = scale;
         p.pyr = pyr; p.w4 = cb ? W<float>(cb->w_off) : nullptr; p.b4 = cb ? W<float>(cb->b_off) : nullptr;
         p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
-        p.B = h->B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
+        p.B = B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
         o.ntiles = conv_out_tiles(p);
         const bool main_variant = conv_v4_eligible(p);        // the dominant kernel (conv_v4_kernel, large maps)
         if (h->profile && (main_variant || (h->profile_all && conv_v2_eligible(p)))) {
@@ -376,7 +389,7 @@ struct Fwd {
             h->prof_events.push_back({e0, e1});
             h->prof_flops.push_back(fl); h->prof_main.push_back(main_variant);
             {   // algorithmic HBM bytes of this launch: every operand once (input, shortcut input, residual, output, weights)
-                const double es = (double)dtype_size(a.dtype), px = (double)h->B * a.H * a.W;
+                const double es = (double)dtype_size(a.dtype), px = (double)B * a.H * a.W;
                 double by = px * (w.cin + (w2 ? w2->cin : 0)) * es + px * w.cout * dtype_size(out_dtype) * (res ? 2.0 : 1.0);
                 by += (double)w.ntaps * w.cin * w.cout * es + (w2 ? (double)w2->cin * w2->cout * es : 0.0);
                 if (pyr) by += px * 4 * 4;
@@ -403,8 +416,8 @@ struct Fwd {
             Act hr = new_act(x.C, H2, W2, dt, false);
             xr = new_act(x.C, H2, W2, dt, false);
             if (!h->dry) {
-                if (r.up) launch_fir_up2(x.p, dt, coef0, 1, hr.p, xr.p, h->B, x.H, x.W, x.C, s);
-                else      launch_fir_down2(x.p, dt, coef0, 1, hr.p, xr.p, h->B, x.H, x.W, x.C, s);
+                if (r.up) launch_fir_up2(x.p, dt, coef0, 1, hr.p, xr.p, B, x.H, x.W, x.C, s);
+                else      launch_fir_down2(x.p, dt, coef0, 1, hr.p, xr.p, B, x.H, x.W, x.C, s);
             }
             hcur = conv(hr, nullptr, nullptr, 0, r.c0, temb, nullptr, 1.f, nullptr, nullptr, dt, true);
             sx0 = &xr; sx1 = nullptr;
@@ -425,7 +438,7 @@ struct Fwd {
         Act k = conv(x, nullptr, coef, 0, aw.k, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
         Act v = conv(x, nullptr, coef, 0, aw.v, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
         Act a = new_act(x.C, x.H, x.W, dt, false);
-        if (!h->dry) launch_attention(q.p, k.p, v.p, a.p, dt, h->B, x.H * x.W, x.C, s);
+        if (!h->dry) launch_attention(q.p, k.p, v.p, a.p, dt, B, x.H * x.W, x.C, s);
         return conv(a, nullptr, nullptr, 0, aw.o, nullptr, &x, 0.70710678118654752440f, nullptr, nullptr, dt, true);
     }
 
@@ -434,27 +447,29 @@ struct Fwd {
         use_handle* H = h;
         const use_config& c = H->cfg;
         const int L = c.n_levels, nrb = c.num_res_blocks, dt = H->act_dtype;
-        H->arena.reset(); H->flops = 0.0; H->debug.clear();
+        arena->reset();
+        if (primary) { H->flops = 0.0; H->debug.clear(); H->debug_B = B; }
         Act xin; xin.p = (void*)x4; xin.C = 4; xin.H = c.n_freq; xin.W = H->T; xin.dtype = DT_F32;
         std::vector<Act> hs;
         hs.push_back(conv(xin, nullptr, nullptr, 0, H->conv_in, nullptr, nullptr, 1.f, nullptr, nullptr, dt, true));
-        H->debug["h_in"] = hs.back();
+        if (primary) H->debug["h_in"] = hs.back();
         Act ipyr = xin;
         size_t ri = 0, ci = 0;
         for (int lvl = 0; lvl < L; ++lvl) {
             for (int k = 0; k < nrb; ++k) hs.push_back(resblock(hs.back(), nullptr, H->res[ri++]));
+            if (lvl == 2 && ev_stagger && !H->dry) (void)hipEventRecord(ev_stagger, s);   // small, latency-bound maps follow
             if (lvl != L - 1) {
                 Act nip = new_act(4, ipyr.H / 2, ipyr.W / 2, DT_F32, false);          // pyramid_downsample
-                if (!H->dry) launch_fir_down2(ipyr.p, DT_F32, nullptr, 0, nullptr, nip.p, H->B, ipyr.H, ipyr.W, 4, s);
+                if (!H->dry) launch_fir_down2(ipyr.p, DT_F32, nullptr, 0, nullptr, nip.p, B, ipyr.H, ipyr.W, 4, s);
                 ipyr = nip;
                 hs.push_back(resblock(hs.back(), nullptr, H->res[ri++], (const float*)ipyr.p, &H->combines[ci++]));
             }
         }
-        H->debug["down_out"] = hs.back();
+        if (primary) H->debug["down_out"] = hs.back();
         Act hc = resblock(hs.back(), nullptr, H->res[ri++]);
-        H->debug["pre_attn"] = hc;
+        if (primary) H->debug["pre_attn"] = hc;
         hc = attention(hc, H->attn);
-        H->debug["post_attn"] = hc;
+        if (primary) H->debug["post_attn"] = hc;
         hc = resblock(hc, nullptr, H->res[ri++]);
         Act pyr; bool have_pyr = false; size_t pi = 0;
         for (int lvl = L - 1; lvl >= 0; --lvl) {
@@ -469,13 +484,13 @@ struct Fwd {
                 have_pyr = true;
             } else {
                 Act up = new_act(4, pyr.H * 2, pyr.W * 2, DT_F32, false);               // pyramid_upsample
-                if (!H->dry) launch_fir_up2(pyr.p, DT_F32, nullptr, 0, nullptr, up.p, H->B, pyr.H, pyr.W, 4, s);
+                if (!H->dry) launch_fir_up2(pyr.p, DT_F32, nullptr, 0, nullptr, up.p, B, pyr.H, pyr.W, 4, s);
                 pyr = conv(hc, nullptr, coef, 1, pw.conv, nullptr, &up, 1.f, nullptr, nullptr, DT_F32, false);
             }
             if (lvl != 0) hc = resblock(hc, nullptr, H->res[ri++]);
         }
-        H->debug["h_last"] = hc;
-        H->debug["pyramid"] = pyr;
+        if (primary) H->debug["h_last"] = hc;
+        if (primary) H->debug["pyramid"] = pyr;
         return pyr;
     }
 };
@@ -493,12 +508,40 @@ static void run_temb(use_handle* h, const float* t, int n, float* silu_buf, floa
 // score = -net(cat[x, y], t): x, y device complex64
 static void run_score(use_handle* h, const float2* x, const float2* y, const float* tembias, int temb_bstride,
                       const float* t, int t_stride, float2* out, hipStream_t s) {
-    const long npix = (long)h->B * h->cfg.n_freq * h->T;
-    launch_pack_input(x, y, h->x4, npix, s);
-    Fwd f{h, s, tembias, temb_bstride, t, t_stride};
-    Act pyr = f.run(h->x4);
-    launch_score_out((const float*)pyr.p, t, t_stride, (const float*)(h->blob + h->outw_off),
-                     (const float*)(h->blob + h->outb_off), out, h->B, (long)h->cfg.n_freq * h->T, s);
+    const long n_per_b = (long)h->cfg.n_freq * h->T;
+    launch_pack_input(x, y, h->x4, (long)h->B * n_per_b, s);
+    const float* outw = (const float*)(h->blob + h->outw_off); const float* outb = (const float*)(h->blob + h->outb_off);
+    Fwd f0{h, s, tembias, temb_bstride, t, t_stride};
+    f0.B = h->B0; f0.arena = &h->arena;
+    if (!h->B1) {
+        Act pyr = f0.run(h->x4);
+        launch_score_out((const float*)pyr.p, t, t_stride, outw, outb, out, h->B, n_per_b, s);
+        return;
+    }
+    // Two sub-batches on two streams.  The items are independent inside the network (GroupNorm is per item), so this is a
+    // pure re-scheduling: the second half starts when the first has finished its large down-path maps, and from then on
+    // the latency-bound kernels of one half (small maps, GroupNorm finalisation, attention: a few workgroups each)
+    // execute beside the large convolutions of the other half instead of leaving the chip idle.
+    const bool overlap = !h->profile;                         // per-launch timing wants the kernels one at a time
+    hipStream_t s2 = overlap ? h->aux_stream : s;
+    if (overlap) {
+        (void)hipEventRecord(h->ev_fork, s);
+        (void)hipStreamWaitEvent(s2, h->ev_fork, 0);
+        f0.ev_stagger = h->ev_stagger;
+    }
+    Act pyr0 = f0.run(h->x4);
+    launch_score_out((const float*)pyr0.p, t, t_stride, outw, outb, out, h->B0, n_per_b, s);
+    if (overlap) (void)hipStreamWaitEvent(s2, h->ev_stagger, 0);
+    const int b0 = h->B0;
+    Fwd f1{h, s2, tembias + (size_t)b0 * temb_bstride, temb_bstride, t + (size_t)b0 * t_stride, t_stride};
+    f1.B = h->B1; f1.arena = &h->arena1; f1.primary = false;
+    Act pyr1 = f1.run(h->x4 + (size_t)b0 * n_per_b * 4);
+    launch_score_out((const float*)pyr1.p, t + (size_t)b0 * t_stride, t_stride, outw, outb, out + (size_t)b0 * n_per_b, h->B1,
+                     n_per_b, s2);
+    if (overlap) {
+        (void)hipEventRecord(h->ev_join, s2);
+        (void)hipStreamWaitEvent(s, h->ev_join, 0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -605,6 +648,7 @@ extern "C" {
 
 int use_set_option(const char* name, long long value) {
     if (!name) return fail(USE_E_INVALID, "option name is null");
+    if (!strcmp(name, "subbatch")) { g_subbatch = value != 0; return USE_OK; }    // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
     return fail(USE_E_INVALID, "unknown option '%s'", name);
 }
@@ -633,6 +677,10 @@ int use_destroy(use_handle* h) {
     (void)hipDeviceSynchronize();
     drop_graphs(h);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->aux_stream) {
+        (void)hipStreamDestroy(h->aux_stream);
+        (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_stagger); (void)hipEventDestroy(h->ev_join);
+    }
     if (h->blob) (void)hipFree(h->blob);
     if (h->arena.base) (void)hipFree(h->arena.base);
     if (h->persist) (void)hipFree(h->persist);
@@ -709,14 +757,30 @@ int use_plan(use_handle* h, int B, int Tpad) {
     HIPCHK(hipDeviceSynchronize());
     drop_graphs(h);
     h->B = B; h->T = Tpad; h->sampler_set = false;
-    // dry run to size the activation arena
+    // sub-batch pipelining: from 4 items up the batch runs as two halves (run_score); "subbatch" option 0 turns it off
+    h->B0 = B; h->B1 = 0;
+    if (g_subbatch && B >= 4) { h->B0 = (B + 1) / 2; h->B1 = B - h->B0; }
+    // dry runs to size the activation arenas (one per sub-batch, carved from one allocation)
     if (h->arena.base) { HIPCHK(hipFree(h->arena.base)); h->arena.base = nullptr; }
-    h->arena.cap = 0; h->arena.peak = 0; h->dry = true;
-    { Fwd f{h, nullptr, nullptr, 0, nullptr, 0}; f.run(nullptr); }
+    h->arena = Arena{}; h->arena1 = Arena{};
+    h->dry = true;
+    { Fwd f{h, nullptr, nullptr, 0, nullptr, 0}; f.B = h->B0; f.arena = &h->arena; f.run(nullptr); }
+    const double flops0 = h->flops;
+    if (h->B1) { Fwd f{h, nullptr, nullptr, 0, nullptr, 0}; f.B = h->B1; f.arena = &h->arena1; f.primary = false; f.run(nullptr); }
+    (void)flops0;
     h->dry = false;
-    h->arena.cap = h->arena.peak + 4096;
-    if (hipMalloc((void**)&h->arena.base, h->arena.cap) != hipSuccess)
-        return fail(USE_E_NOMEM, "cannot allocate %.1f MB of activation workspace", h->arena.cap / 1e6);
+    const size_t cap0 = (h->arena.peak + 4096 + 255) & ~(size_t)255, cap1 = h->B1 ? h->arena1.peak + 4096 : 0;
+    char* base = nullptr;
+    if (hipMalloc((void**)&base, cap0 + cap1) != hipSuccess)
+        return fail(USE_E_NOMEM, "cannot allocate %.1f MB of activation workspace", (cap0 + cap1) / 1e6);
+    h->arena.base = base; h->arena.cap = cap0 + cap1;         // owns the allocation (use_workspace_bytes reports cap)
+    h->arena1.base = h->B1 ? base + cap0 : nullptr; h->arena1.cap = cap1;
+    if (h->B1 && !h->aux_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_stagger, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
     // persistent buffers
     const size_t n = (size_t)B * h->cfg.n_freq * Tpad;
     h->lang_blocks = (int)std::min<size_t>(256, ((size_t)h->cfg.n_freq * Tpad + 255) / 256);
@@ -925,7 +989,7 @@ int use_debug_tensor(use_handle* h, const char* name, void** dev_ptr, int* dims4
     auto it = h->debug.find(name);
     if (it == h->debug.end()) return fail(USE_E_INVALID, "no debug tensor '%s'", name);
     if (dev_ptr) *dev_ptr = it->second.p;
-    if (dims4) { dims4[0] = h->B; dims4[1] = it->second.H; dims4[2] = it->second.W; dims4[3] = it->second.C; }
+    if (dims4) { dims4[0] = h->debug_B; dims4[1] = it->second.H; dims4[2] = it->second.W; dims4[3] = it->second.C; }
     if (dtype) *dtype = it->second.dtype;
     return USE_OK;
 }
