@@ -11,6 +11,10 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 640
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+from universal_speech_enhancement_amd.hip_engine import set_option
+for env, opt in (("USE_SUBBATCH", "subbatch"), ("USE_STAGGER", "stagger_level")):      # A/B of the scheduling knobs
+    if os.environ.get(env):
+        set_option(opt, int(os.environ[env]))
 eng = HipScoreEngine(precision=prec)
 eng.load_state_dict(tw.make_state_dict(1234, **tw.LARGE))
 x = torch.from_numpy(tn.complex_normal(1, "x", (B, 1, 512, T))).cuda() * 0.5

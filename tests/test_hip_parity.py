@@ -80,6 +80,26 @@ def test_score_golden_with_wide_tile_kernel_forced(golden_dir, engines, prec, to
         set_option("no_such_option", 1)
 
 
+def test_subbatch_pipelining_is_a_pure_rescheduling(sd_np):
+    """Batches of >= 4 items run as staggered sub-batches on separate streams: bit-identical to the unsplit evaluation."""
+    from universal_speech_enhancement_amd.hip_engine import HipScoreEngine, set_option
+    x = torch.from_numpy(tnoise.complex_normal(5, "x", (5, 1, 512, 64))).cuda() * 0.5
+    y = torch.from_numpy(tnoise.complex_normal(5, "y", (5, 1, 512, 64))).cuda() * 0.5
+    t = torch.linspace(0.9, 0.1, 5).cuda()
+    outs = []
+    try:
+        for n in (1, 2, 4):
+            set_option("subbatch", n)
+            e = HipScoreEngine(precision="bf16")
+            e.load_state_dict(sd_np)
+            outs.append(e.score(x, y, t).clone())
+            e.close()
+    finally:
+        set_option("subbatch", 2)
+    assert torch.isfinite(torch.view_as_real(outs[0])).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_intermediate_taps_match_oracle_fp32(golden_dir, engines, sd_np):
     g = dict(np.load(os.path.join(golden_dir, "forward_large.npz")))
     x = torch.from_numpy(g["x"])

@@ -57,6 +57,8 @@ struct PyrW { GNW gn; ConvW conv; };
 
 struct Expected { std::string name; std::vector<int64_t> shape; };
 
+constexpr int MAX_SUB = 4;                       // sub-batches of the pipelined evaluation (run_score)
+
 struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, dtype = DT_F32; float* stats = nullptr; int ntiles = 0; };
 
 struct Arena {
@@ -108,10 +110,11 @@ struct use_handle {
     hipStream_t cap_stream = nullptr;
     // sub-batch pipelining (see run_score): the batch is evaluated as two halves on two streams, the second started when
     // the first reaches its small feature maps, so that one half's latency-bound kernels hide behind the other's large ones
-    int B0 = 0, B1 = 0;                          // sub-batch sizes (B1 = 0: not split)
-    Arena arena1;                                // workspace of the second sub-batch (inside the same allocation)
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_stagger = nullptr, ev_join = nullptr;
+    int nsub = 1, sub_B[MAX_SUB] = {0, 0, 0, 0};  // sub-batch sizes (nsub = 1: not split)
+    Arena sub_arena[MAX_SUB];                    // workspaces of sub-batches 1.. (inside the same allocation as `arena`)
+    hipStream_t aux_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_stagger[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr},
+               ev_join[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
     int debug_B = 0;
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // [0]: device RNG, [1]: injected noise
     hipGraphExec_t score_graph = nullptr;
@@ -330,7 +333,8 @@ static int pack_all(use_handle* h, char* blob) {
 // ---------------------------------------------------------------------------------------------------------
 // forward pass (one score-network evaluation)
 // ---------------------------------------------------------------------------------------------------------
-static bool g_subbatch = true;                   // use_set_option("subbatch", 0/1)
+static int g_subbatch = 2;                       // use_set_option("subbatch", n): sub-batches per evaluation (0/1: off)
+static int g_stagger_level = 2;                  // use_set_option("stagger_level", l): the next sub-batch starts after level l
 
 struct Fwd {
     use_handle* h; hipStream_t s;
@@ -457,7 +461,7 @@ struct Fwd {
         size_t ri = 0, ci = 0;
         for (int lvl = 0; lvl < L; ++lvl) {
             for (int k = 0; k < nrb; ++k) hs.push_back(resblock(hs.back(), nullptr, H->res[ri++]));
-            if (lvl == 2 && ev_stagger && !H->dry) (void)hipEventRecord(ev_stagger, s);   // small, latency-bound maps follow
+            if (lvl == std::min(g_stagger_level, L - 1) && ev_stagger && !H->dry) (void)hipEventRecord(ev_stagger, s);   // small maps follow
             if (lvl != L - 1) {
                 Act nip = new_act(4, ipyr.H / 2, ipyr.W / 2, DT_F32, false);          // pyramid_downsample
                 if (!H->dry) launch_fir_down2(ipyr.p, DT_F32, nullptr, 0, nullptr, nip.p, B, ipyr.H, ipyr.W, 4, s);
@@ -511,37 +515,37 @@ static void run_score(use_handle* h, const float2* x, const float2* y, const flo
     const long n_per_b = (long)h->cfg.n_freq * h->T;
     launch_pack_input(x, y, h->x4, (long)h->B * n_per_b, s);
     const float* outw = (const float*)(h->blob + h->outw_off); const float* outb = (const float*)(h->blob + h->outb_off);
-    Fwd f0{h, s, tembias, temb_bstride, t, t_stride};
-    f0.B = h->B0; f0.arena = &h->arena;
-    if (!h->B1) {
+    if (h->nsub == 1) {
+        Fwd f0{h, s, tembias, temb_bstride, t, t_stride};
+        f0.B = h->B; f0.arena = &h->arena;
         Act pyr = f0.run(h->x4);
         launch_score_out((const float*)pyr.p, t, t_stride, outw, outb, out, h->B, n_per_b, s);
         return;
     }
-    // Two sub-batches on two streams.  The items are independent inside the network (GroupNorm is per item), so this is a
-    // pure re-scheduling: the second half starts when the first has finished its large down-path maps, and from then on
-    // the latency-bound kernels of one half (small maps, GroupNorm finalisation, attention: a few workgroups each)
-    // execute beside the large convolutions of the other half instead of leaving the chip idle.
+    // Sub-batches on separate streams.  The items are independent inside the network (GroupNorm is per item), so this is
+    // a pure re-scheduling: sub-batch i+1 starts when sub-batch i has finished its large down-path maps, and from then on
+    // the latency-bound kernels of one sub-batch (small maps, GroupNorm finalisation, attention: a few workgroups each)
+    // execute beside the large convolutions of another instead of leaving the chip idle.
     const bool overlap = !h->profile;                         // per-launch timing wants the kernels one at a time
-    hipStream_t s2 = overlap ? h->aux_stream : s;
-    if (overlap) {
-        (void)hipEventRecord(h->ev_fork, s);
-        (void)hipStreamWaitEvent(s2, h->ev_fork, 0);
-        f0.ev_stagger = h->ev_stagger;
+    if (overlap) (void)hipEventRecord(h->ev_fork, s);
+    int b0 = 0;
+    for (int i = 0; i < h->nsub; ++i) {
+        hipStream_t si = (i == 0 || !overlap) ? s : h->aux_stream[i];
+        if (overlap && i) {
+            (void)hipStreamWaitEvent(si, h->ev_fork, 0);
+            (void)hipStreamWaitEvent(si, h->ev_stagger[i - 1], 0);
+        }
+        Fwd f{h, si, tembias + (size_t)b0 * temb_bstride, temb_bstride, t + (size_t)b0 * t_stride, t_stride};
+        f.B = h->sub_B[i]; f.arena = i ? &h->sub_arena[i] : &h->arena; f.primary = i == 0;
+        if (overlap && i + 1 < h->nsub) f.ev_stagger = h->ev_stagger[i];
+        Act pyr = f.run(h->x4 + (size_t)b0 * n_per_b * 4);
+        launch_score_out((const float*)pyr.p, t + (size_t)b0 * t_stride, t_stride, outw, outb, out + (size_t)b0 * n_per_b,
+                         h->sub_B[i], n_per_b, si);
+        if (overlap && i) (void)hipEventRecord(h->ev_join[i], si);
+        b0 += h->sub_B[i];
     }
-    Act pyr0 = f0.run(h->x4);
-    launch_score_out((const float*)pyr0.p, t, t_stride, outw, outb, out, h->B0, n_per_b, s);
-    if (overlap) (void)hipStreamWaitEvent(s2, h->ev_stagger, 0);
-    const int b0 = h->B0;
-    Fwd f1{h, s2, tembias + (size_t)b0 * temb_bstride, temb_bstride, t + (size_t)b0 * t_stride, t_stride};
-    f1.B = h->B1; f1.arena = &h->arena1; f1.primary = false;
-    Act pyr1 = f1.run(h->x4 + (size_t)b0 * n_per_b * 4);
-    launch_score_out((const float*)pyr1.p, t + (size_t)b0 * t_stride, t_stride, outw, outb, out + (size_t)b0 * n_per_b, h->B1,
-                     n_per_b, s2);
-    if (overlap) {
-        (void)hipEventRecord(h->ev_join, s2);
-        (void)hipStreamWaitEvent(s, h->ev_join, 0);
-    }
+    if (overlap)
+        for (int i = 1; i < h->nsub; ++i) (void)hipStreamWaitEvent(s, h->ev_join[i], 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -648,7 +652,8 @@ extern "C" {
 
 int use_set_option(const char* name, long long value) {
     if (!name) return fail(USE_E_INVALID, "option name is null");
-    if (!strcmp(name, "subbatch")) { g_subbatch = value != 0; return USE_OK; }    // takes effect at the next use_plan
+    if (!strcmp(name, "subbatch")) { g_subbatch = (int)value; return USE_OK; }          // takes effect at the next use_plan
+    if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
     return fail(USE_E_INVALID, "unknown option '%s'", name);
 }
@@ -677,10 +682,11 @@ int use_destroy(use_handle* h) {
     (void)hipDeviceSynchronize();
     drop_graphs(h);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-    if (h->aux_stream) {
-        (void)hipStreamDestroy(h->aux_stream);
-        (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_stagger); (void)hipEventDestroy(h->ev_join);
+    for (int i = 0; i < MAX_SUB; ++i) {
+        if (h->aux_stream[i]) (void)hipStreamDestroy(h->aux_stream[i]);
+        if (h->ev_stagger[i]) { (void)hipEventDestroy(h->ev_stagger[i]); (void)hipEventDestroy(h->ev_join[i]); }
     }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->blob) (void)hipFree(h->blob);
     if (h->arena.base) (void)hipFree(h->arena.base);
     if (h->persist) (void)hipFree(h->persist);
@@ -757,29 +763,38 @@ int use_plan(use_handle* h, int B, int Tpad) {
     HIPCHK(hipDeviceSynchronize());
     drop_graphs(h);
     h->B = B; h->T = Tpad; h->sampler_set = false;
-    // sub-batch pipelining: from 4 items up the batch runs as two halves (run_score); "subbatch" option 0 turns it off
-    h->B0 = B; h->B1 = 0;
-    if (g_subbatch && B >= 4) { h->B0 = (B + 1) / 2; h->B1 = B - h->B0; }
+    // sub-batch pipelining (run_score): `subbatch` sub-batches of at least 2 items each
+    h->nsub = std::max(1, std::min(std::min(g_subbatch, MAX_SUB), B / 2));
+    for (int i = 0; i < MAX_SUB; ++i) h->sub_B[i] = i < h->nsub ? B / h->nsub + (i < B % h->nsub ? 1 : 0) : 0;
     // dry runs to size the activation arenas (one per sub-batch, carved from one allocation)
     if (h->arena.base) { HIPCHK(hipFree(h->arena.base)); h->arena.base = nullptr; }
-    h->arena = Arena{}; h->arena1 = Arena{};
+    h->arena = Arena{};
     h->dry = true;
-    { Fwd f{h, nullptr, nullptr, 0, nullptr, 0}; f.B = h->B0; f.arena = &h->arena; f.run(nullptr); }
-    const double flops0 = h->flops;
-    if (h->B1) { Fwd f{h, nullptr, nullptr, 0, nullptr, 0}; f.B = h->B1; f.arena = &h->arena1; f.primary = false; f.run(nullptr); }
-    (void)flops0;
+    size_t caps[MAX_SUB] = {0, 0, 0, 0}, total = 0;
+    for (int i = 0; i < h->nsub; ++i) {
+        Arena& ar = i ? h->sub_arena[i] : h->arena;
+        ar = Arena{};
+        Fwd f{h, nullptr, nullptr, 0, nullptr, 0};
+        f.B = h->sub_B[i]; f.arena = &ar; f.primary = i == 0;
+        f.run(nullptr);
+        caps[i] = (ar.peak + 4096 + 255) & ~(size_t)255; total += caps[i];
+    }
     h->dry = false;
-    const size_t cap0 = (h->arena.peak + 4096 + 255) & ~(size_t)255, cap1 = h->B1 ? h->arena1.peak + 4096 : 0;
     char* base = nullptr;
-    if (hipMalloc((void**)&base, cap0 + cap1) != hipSuccess)
-        return fail(USE_E_NOMEM, "cannot allocate %.1f MB of activation workspace", (cap0 + cap1) / 1e6);
-    h->arena.base = base; h->arena.cap = cap0 + cap1;         // owns the allocation (use_workspace_bytes reports cap)
-    h->arena1.base = h->B1 ? base + cap0 : nullptr; h->arena1.cap = cap1;
-    if (h->B1 && !h->aux_stream) {
-        HIPCHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_stagger, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    if (hipMalloc((void**)&base, total) != hipSuccess)
+        return fail(USE_E_NOMEM, "cannot allocate %.1f MB of activation workspace", total / 1e6);
+    h->arena.base = base; h->arena.cap = total;               // owns the allocation (use_workspace_bytes reports cap)
+    {
+        size_t off = caps[0];
+        for (int i = 1; i < h->nsub; ++i) { h->sub_arena[i].base = base + off; h->sub_arena[i].cap = caps[i]; off += caps[i]; }
+    }
+    if (h->nsub > 1 && !h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < h->nsub; ++i) {
+        if (i && !h->aux_stream[i]) HIPCHK(hipStreamCreateWithFlags(&h->aux_stream[i], hipStreamNonBlocking));
+        if (h->nsub > 1 && !h->ev_stagger[i]) {
+            HIPCHK(hipEventCreateWithFlags(&h->ev_stagger[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        }
     }
     // persistent buffers
     const size_t n = (size_t)B * h->cfg.n_freq * Tpad;
