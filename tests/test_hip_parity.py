@@ -80,6 +80,20 @@ def test_score_golden_with_wide_tile_kernel_forced(golden_dir, engines, prec, to
         set_option("no_such_option", 1)
 
 
+def test_odd_widths_at_the_bottom_of_the_unet_fp32(engines, sd_np):
+    """T' = 192 = 3 x 64: feature-map widths 192, 96, 48, 24, 12, 6, 3 -- partially filled tiles in every conv kernel
+    (conv_v4 at 512x192, conv_v2 at 48 / 24 columns, conv_kernel at 12 / 6 / 3) and odd FIR sizes.  Against the CPU oracle."""
+    x = torch.from_numpy(tnoise.complex_normal(21, "x", (1, 1, 512, 192))) * 0.5
+    y = torch.from_numpy(tnoise.complex_normal(21, "y", (1, 1, 512, 192))) * 0.5
+    t = torch.tensor([0.37])
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    with torch.no_grad():
+        ref = no.ncsnpp_forward(sd, torch.cat([x, y], dim=1), t)
+    out = engines["fp32"].score(x.cuda(), y.cuda(), t.cuda())
+    err = _relmax(out, -ref)
+    assert err < 5e-4, err
+
+
 def test_subbatch_pipelining_is_a_pure_rescheduling(sd_np):
     """Batches of >= 4 items run as staggered sub-batches on separate streams: bit-identical to the unsplit evaluation."""
     from universal_speech_enhancement_amd.hip_engine import HipScoreEngine, set_option
