@@ -100,7 +100,12 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="skip the timed sampler steps; run only the per-launch measurement of the dominant kernel (for "
+                         "`rocprofv3 --kernel-trace --stats -- python bench.py --roofline-only`, see profiles/README.md)")
     a = ap.parse_args()
+    if a.roofline_only:
+        a.steps, a.warmup, a.no_cpu_baseline = 0, 0, True
 
     from universal_speech_enhancement_amd import distributed as D
     from universal_speech_enhancement_amd.hip_engine import HipScoreEngine
@@ -145,11 +150,14 @@ def main():
         out = eng.sample(Y, seed=4321 + a.warmup + k)
     barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, device=dev)
-    assert torch.isfinite(torch.view_as_real(out)).all(), "non-finite sampler output"
+    if a.steps:
+        assert torch.isfinite(torch.view_as_real(out)).all(), "non-finite sampler output"
+    else:
+        out = torch.zeros_like(Y)
 
     frames = world * B * T * a.steps
     value = frames / dt
-    ms_per_step = dt / a.steps * 1e3
+    ms_per_step = dt / max(a.steps, 1) * 1e3
     padded_frame_nfe_per_s = world * B * Tp * nfe * a.steps / dt
     tflops_path = padded_frame_nfe_per_s * FLOP_PER_FRAME_NFE / 1e12 / world     # per GPU
 
@@ -175,6 +183,9 @@ def main():
                 "algorithmic_hbm_bytes_per_launch": round(conv_bytes / max(conv_launches, 1)),
                 "kernel": "use::conv_v4_kernel<%s> (wide-tile implicit-GEMM 3x3 conv of the large maps, both ACT variants)"
                           % ("bf16,bf16,32" if a.precision == "bf16" else "f32,f32,16"),
+                "measured": "HIP events around every launch of one eager score evaluation with the sub-batches run back to back "
+                            "(one launch on the chip at a time; `rocprofv3 --stats -- python bench.py --roofline-only` agrees); in "
+                            "the timed region the same launches share the chip with the other sub-batch's kernels",
                 "launches_per_score": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                 "algorithmic_gflop_per_launch": round(conv_flops / max(conv_launches, 1) / 1e9, 2),
                 "kernel_time_share_of_score": round(conv_ms / total_ms, 3),

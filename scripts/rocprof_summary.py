@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Summarise `rocprofv3 --kernel-trace --stats --output-format csv` output (scripts/run_profile.sh) per kernel.
-usage: rocprof_summary.py <dir-with-*_kernel_stats.csv> [bench-json-line-file]"""
+usage: rocprof_summary.py <dir-with-*_kernel_stats.csv> [bench-json-line-file] [profiled command]"""
 import csv, glob, os, sys
 
 d = sys.argv[1]
 f = sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True))[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline` ({os.path.basename(f)})")
+cmd = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+print(f"# rocprofv3 --kernel-trace --stats of `{cmd}` ({os.path.basename(f)})")
 print(f"# total kernel time {tot / 1e6:.2f} ms over {sum(int(r['Calls']) for r in rows)} launches")
 print(f"{'total ms':>10} {'%':>6} {'calls':>7} {'avg us':>9} {'min us':>8} {'max us':>8}  kernel")
 for r in rows[:24]:
