@@ -45,6 +45,11 @@ typedef struct use_config {
     int n_freq;            /* F = n_fft/2+1 = 512                                SGMSE_Large.yaml:11     */
     int precision;         /* USE_PREC_*: activation/weight storage; accumulation is always fp32        */
     float theta, sigma_min, sigma_max; /* OUVE SDE (1.5, 0.05, 0.5)              sdes.py:184             */
+    /* NCSNpp(discriminative=True), the generator of the LSGAN refine stage (ncsnpp.py:86-92,
+     * GAN/generator/ncsnpp/model_wrapper.py:54): 0 everywhere = the score network above */
+    int input_channels;    /* real input channels: 0 or 4 = (x.re, x.im, y.re, y.im); 2 = (y.re, y.im)  ncsnpp.py:63,92 */
+    int unconditional;     /* 1: no time embedding (conditional=False)                                 ncsnpp.py:89   */
+    int no_sigma_scale;    /* 1: output not divided by t (scale_by_sigma=False)                        ncsnpp.py:90   */
 } use_config;
 
 typedef struct use_sampler_config {
@@ -102,6 +107,11 @@ int use_sde_predictor(use_handle* h, int predictor, float t, int N, const void* 
                       const void* noise, uint64_t seed, void* x_out, void* x_mean, int64_t n, use_stream_t s);
 int use_sde_corrector(use_handle* h, int corrector, float t, float snr, int B, const void* x, const void* score,
                       const void* noise, uint64_t seed, void* x_out, void* x_mean, int64_t n, use_stream_t s);
+
+/* Raw backbone output NCSNpp.forward(cat[x, y], t) (ncsnpp.py:324-501), i.e. without the sign flip of use_score.
+ * x, y: complex64 [B,1,F,T'] device; y must be null when input_channels == 2 (the input is x alone), t must be null when
+ * the handle is unconditional and may be null when it is conditional only if no_sigma_scale... (not supported: give t). */
+int use_forward(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream);
 
 /* Introspection for tests / profiling */
 /* One eager score evaluation with a HIP-event pair around every launch of the dominant kernel (conv_v4_kernel, the

@@ -17,6 +17,8 @@ Fixtures
   sampler_*.npz     get_pc_sampler with an analytic score_fn, N=7                    (G3)
   sample_e2e.npz    ScoreModel.sample, 0.4 s utterance, N=3, langevin x1             (G4)
   sample_cfg1.npz   BASELINE cfg1: 2 s utterance, N=5, reverse_diffusion+langevin    (G5, ~70 s)
+  refine.npz        LSGAN refine generator: NCSNpp(discriminative=True).forward [2,1,512,64] and
+                    NCSNPP_Wrapper inference on 2 x 0.4 s                           
 """
 import argparse
 import os
@@ -186,12 +188,29 @@ def gen_sample_cfg1(model=None):
     _sample_case(m, crc, "sample_cfg1.npz", 1, 48000, 5, 1, seed=1234)
 
 
+def gen_refine(model=None):
+    """LSGAN refine stage: NCSNPP_Wrapper(n_fft=1022, hop=160, num_frames=480) = NCSNpp(discriminative=True)
+    between STFT glue (GAN/generator/ncsnpp/model_wrapper.py:19-121, configs/model/LSGAN.yaml:46-53)."""
+    from src.models.components.GAN.generator.ncsnpp.model_wrapper import NCSNPP_Wrapper
+    w = NCSNPP_Wrapper(n_fft=1022, hop_length=160, num_frames=480, window="hann", spec_factor=0.15, spec_abs_exponent=0.5).eval()
+    sd = tw.make_state_dict(4321, **tw.REFINE)
+    w.net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    crc = tw.weights_checksum(sd)
+    x = torch.from_numpy(tnoise.complex_normal(13, "refine_x", (2, 1, 512, 64))) * 0.5
+    wav = torch.from_numpy(tnoise.synth_noisy_speech(2, 9600, seed=77))
+    with torch.no_grad():
+        out = w.net(x)
+        fake = w({"perturbed": wav.clone()})["fake"]
+    np.savez(os.path.join(OUT, "refine.npz"), x=x.numpy(), out=out.numpy(), wav=wav.numpy(), fake=fake.numpy(),
+             weights_seed=4321, weights_crc=crc)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    small = {"fir": gen_fir, "resblocks": gen_resblocks, "attn": gen_attn, "samplers": gen_samplers}
+    small = {"fir": gen_fir, "resblocks": gen_resblocks, "attn": gen_attn, "samplers": gen_samplers, "refine": gen_refine}
     big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1}
     todo = [a.only] if a.only else list(small) + list(big)
     model = build_reference_large() if any(n in big for n in todo) else None

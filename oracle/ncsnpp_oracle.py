@@ -116,22 +116,32 @@ def ncsnpp_forward(
     ch_mult: Sequence[int] = (1, 1, 2, 2, 2, 2, 2),
     num_res_blocks: int = 2,
     taps: Optional[dict] = None,
+    discriminative: bool = False,
 ) -> torch.Tensor:
     """NCSNpp.forward (ncsnpp.py:324-501) for the predict-path configuration
     (biggan blocks, fir, output_skip / input_skip 'sum', fourier, scale_by_sigma, not centered).
 
     x: complex64 [B, 2, F, T] = cat([x_t, Y], dim=1); t: float32 [B].  Returns complex64 [B, 1, F, T].
     ``taps`` (optional dict) receives named intermediates for per-layer parity tests.
+
+    ``discriminative=True`` (ncsnpp.py:86-92; the generator of the LSGAN refine stage,
+    GAN/generator/ncsnpp/model_wrapper.py:54,114-121): x is complex64 [B, 1, F, T] alone, ``t`` is ignored -- no time
+    embedding (the two Linear layers are absent from the module list, Dense_0 is unused), no division by t.
     """
     L = len(ch_mult)
-    # ncsnpp.py:333-347: channels = (x.re, x.im, y.re, y.im)
-    x4 = torch.cat([x[:, [0]].real, x[:, [0]].imag, x[:, [1]].real, x[:, [1]].imag], dim=1)
-    temb = time_embedding(t, sd)
+    if discriminative:
+        x4 = torch.cat([x[:, [0]].real, x[:, [0]].imag], dim=1)               # ncsnpp.py:333-347 with input_channels = 2
+        temb = None                                                           # ncsnpp.py:352, 364-370
+        m = 1
+    else:
+        # ncsnpp.py:333-347: channels = (x.re, x.im, y.re, y.im)
+        x4 = torch.cat([x[:, [0]].real, x[:, [0]].imag, x[:, [1]].real, x[:, [1]].imag], dim=1)
+        temb = time_embedding(t, sd)
+        m = 3
     x4 = 2 * x4 - 1.0  # ncsnpp.py:372-374
     input_pyramid = x4
-    m = 3
-    hs: List[torch.Tensor] = [F.conv2d(x4, sd["all_modules.3.weight"], sd["all_modules.3.bias"], padding=1)]
-    m = 4
+    hs: List[torch.Tensor] = [F.conv2d(x4, sd[f"all_modules.{m}.weight"], sd[f"all_modules.{m}.bias"], padding=1)]
+    m += 1
     if taps is not None:
         taps["temb"] = temb; taps["h_in"] = hs[0]
     for lvl in range(L):
@@ -165,7 +175,7 @@ def ncsnpp_forward(
     assert not hs
     if taps is not None:
         taps["pyramid"] = pyramid
-    h = pyramid / t[:, None, None, None]                                       # ncsnpp.py:492-494
+    h = pyramid if discriminative else pyramid / t[:, None, None, None]        # ncsnpp.py:492-494
     h = F.conv2d(h, sd["output_layer.weight"], sd["output_layer.bias"])        # ncsnpp.py:497
     return torch.complex(h[:, 0], h[:, 1]).unsqueeze(1)                        # ncsnpp.py:498-500
 

@@ -196,3 +196,14 @@ def score_model_sample(net_forward: Callable, wav: torch.Tensor, N=50, predictor
 
     sample, nfe = pc_sampler(score, Y, N, predictor, corrector, corrector_steps, snr, t_eps, noise)
     return istft(spec_back(sample.squeeze(1)), T_orig), sample, Y, nfe
+
+
+def refine_generator(net_forward: Callable, wav: torch.Tensor, n_fft=1022, hop=160):
+    """NCSNPP_Wrapper.forward, inference branch (GAN/generator/ncsnpp/model_wrapper.py:114-121): the LSGAN refine stage
+    that follows the sampler in the reference's documented pipeline (README.md:175-178; LSGAN_module.py:139-155).
+    ``net_forward(Y_c64[B,1,F,T']) -> c64[B,1,F,T']`` is NCSNpp(discriminative=True)."""
+    T_orig = wav.size(1)
+    Y = pad_spec(spec_fwd(stft(wav, n_fft, hop)).unsqueeze(1))
+    out = net_forward(Y)
+    return istft(spec_back(out.squeeze(1)), T_orig, n_fft, hop), out, Y
+

@@ -173,3 +173,13 @@ def test_predict_config_composition_and_loader(tmp_path):
     assert abs(float(b["perturbed"].abs().max()) - 0.8) < 1e-6
     model = P.instantiate(cfg["model"])
     assert type(model).__name__ == "SGMSEModule" and model.sampler_kwargs == {"N": 30} and model.Score.precision == "fp32"
+    # the refine stage: same config keys as the reference's configs/model/LSGAN.yaml, reference key layout
+    cfg2 = P.compose(["model=LSGAN", "model.G.precision=fp32"])
+    gan = P.instantiate(cfg2["model"])
+    assert type(gan).__name__ == "GANModule" and type(gan.G).__name__ == "NCSNPP_Wrapper" and gan.G.target_len == 479 * 160
+    keys = list(gan.state_dict())
+    assert keys[0] == "G.net.output_layer.weight" and gan.state_dict()["G.net.output_layer.weight"].shape == (2, 2, 1, 1)
+    assert "G.net.all_modules.1.weight" in keys and gan.state_dict()["G.net.all_modules.1.weight"].shape == (128, 2, 3, 3)
+    assert "G.net.all_modules.2.Dense_0.weight" in keys        # present (and unused) in the unconditional network too
+    with pytest.raises(NotImplementedError):
+        gan.G({"clean": torch.zeros(1, 10), "perturbed": torch.zeros(1, 10)})

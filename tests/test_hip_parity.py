@@ -80,6 +80,44 @@ def test_score_golden_with_wide_tile_kernel_forced(golden_dir, engines, prec, to
         set_option("no_such_option", 1)
 
 
+@pytest.mark.parametrize("prec,tol,tol_wav", [("fp32", 5e-4, 2e-3), ("bf16", 6e-2, 1.5e-1)])
+def test_lsgan_refine_generator_matches_reference(golden_dir, prec, tol, tol_wav):
+    """NCSNpp(discriminative=True) through the backbone interface and NCSNPP_Wrapper / GANModule.predict_step
+    through the batch-dict contract, against outputs of the reference itself."""
+    from universal_speech_enhancement_amd.LSGAN_module import GANModule
+    from universal_speech_enhancement_amd.gan.ncsnpp_wrapper import NCSNPP_Wrapper
+    g = dict(np.load(os.path.join(golden_dir, "refine.npz")))
+    sd_np = tw.make_state_dict(int(g["weights_seed"]), **tw.REFINE)
+    w = NCSNPP_Wrapper(n_fft=1022, hop_length=160, num_frames=480, precision=prec)
+    missing, unexpected = w.net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True), None
+    out = w.net(torch.from_numpy(g["x"]).cuda())
+    assert _relmax(out, torch.from_numpy(g["out"])) < tol
+    mod = GANModule(G=w)
+    batch = mod.predict_step({"perturbed": torch.from_numpy(g["wav"]).cuda()})
+    assert batch["fake"].shape == g["fake"].shape
+    assert _relmax(batch["fake"], torch.from_numpy(g["fake"])) < tol_wav
+    with pytest.raises(UseHipError):
+        w.net(torch.from_numpy(g["x"]))                       # CPU tensors: no fallback
+    with pytest.raises(ValueError):
+        w.net(torch.from_numpy(g["x"]).cuda().repeat(1, 2, 1, 1))   # a discriminative network takes Y alone
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", 6e-2)])
+def test_refine_generator_long_sequence_attention(prec, tol):
+    """T' = 128: the bottleneck of the 4-level refine generator is 64 x 16 = 1024 tokens, which takes the GEMM form of the
+    attention core (scores and P.V as implicit GEMMs on conv_kernel + row softmax).  Against the CPU oracle."""
+    from universal_speech_enhancement_amd.sgmse.backbones.ncsnpp import NCSNpp
+    sd_np = tw.make_state_dict(4321, **tw.REFINE)
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    Y = torch.from_numpy(tnoise.complex_normal(31, "Y", (1, 1, 512, 128))) * 0.5
+    with torch.no_grad():
+        ref = no.ncsnpp_forward(sd, Y, None, ch_mult=tw.REFINE["ch_mult"], num_res_blocks=1, discriminative=True)
+    net = NCSNpp(discriminative=True, precision=prec)
+    net.load_state_dict(sd, strict=True)
+    out = net(Y.cuda())
+    assert _relmax(out, ref) < tol, _relmax(out, ref)
+
+
 def test_odd_widths_at_the_bottom_of_the_unet_fp32(engines, sd_np):
     """T' = 192 = 3 x 64: feature-map widths 192, 96, 48, 24, 12, 6, 3 -- partially filled tiles in every conv kernel
     (conv_v4 at 512x192, conv_v2 at 48 / 24 columns, conv_kernel at 12 / 6 / 3) and odd FIR sizes.  Against the CPU oracle."""

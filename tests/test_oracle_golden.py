@@ -95,3 +95,19 @@ def test_sample_e2e_matches_reference(golden_dir, large_sd):
     ref = g["enhanced"]
     err = np.abs(enh.numpy() - ref).max() / np.abs(ref).max()
     assert err < 1e-4, err
+
+
+def test_refine_generator_matches_reference(golden_dir):
+    """LSGAN refine stage: NCSNpp(discriminative=True).forward and the NCSNPP_Wrapper inference branch."""
+    g = _load(golden_dir, "refine.npz")
+    sd_np = tw.make_state_dict(int(g["weights_seed"]), **tw.REFINE)
+    assert str(g["weights_crc"]) == tw.weights_checksum(sd_np)
+    sd = no.to_torch(sd_np)
+    net = lambda Y: no.ncsnpp_forward(sd, Y, None, ch_mult=tw.REFINE["ch_mult"], num_res_blocks=1, discriminative=True)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["x"]))
+        fake, _, _ = so.refine_generator(net, torch.from_numpy(g["wav"]))
+    assert np.abs(out.numpy() - g["out"]).max() / np.abs(g["out"]).max() < 2e-5
+    assert np.abs(fake.numpy() - g["fake"]).max() / np.abs(g["fake"]).max() < 1e-4
+

@@ -20,7 +20,8 @@ CORRECTORS = {"none": 0, "langevin": 1, "ald": 2}
 class UseConfig(C.Structure):
     _fields_ = [("nf", C.c_int), ("n_levels", C.c_int), ("ch_mult", C.c_int * 8), ("num_res_blocks", C.c_int),
                 ("n_freq", C.c_int), ("precision", C.c_int), ("theta", C.c_float), ("sigma_min", C.c_float),
-                ("sigma_max", C.c_float)]
+                ("sigma_max", C.c_float), ("input_channels", C.c_int), ("unconditional", C.c_int),
+                ("no_sigma_scale", C.c_int)]
 
 
 class UseSamplerConfig(C.Structure):
@@ -51,6 +52,7 @@ SYMBOLS = {
     "use_plan": (_i, [_vp, _i, _i]),
     "use_workspace_bytes": (_i, [_vp, C.POINTER(C.c_size_t)]),
     "use_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "use_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "use_set_sampler": (_i, [_vp, C.POINTER(UseSamplerConfig)]),
     "use_num_noise_draws": (_i, [_vp]),
     "use_get_timesteps": (_i, [_vp, C.POINTER(_f), _i]),

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(512) void conv_v3_kernel(ConvArgs p) {
     constexpr int HPITCH = (V3_HE * ROWB / 16 + 15) / 16 * 16 * 16;
     constexpr int HALO_BYTES = V3_HE * HPITCH, W_BYTES = BN * ROWB;
     constexpr int RING0 = 2 * HALO_BYTES;                    // 3 weight slabs follow the 2 halo buffers
-    constexpr int DUMMY0 = RING0 + 3 * W_BYTES;              // end of the staging buffers
+    constexpr int DUMMY0 = RING0 + 3 * W_BYTES;              // end of the staging buffers (trace builds keep their stamps here)
+    (void)DUMMY0;
     constexpr int NPIECE = V3_HE * V3_HE * PARTS;            // 2592 16-byte pieces per halo chunk
     constexpr int HP = (NPIECE + 255) / 256;                 // 11 pieces per helper thread per chunk
     static_assert(PARTS == 8 && HP == 11 && KSTEPS % 2 == 0, "v3 staging layout");

@@ -47,6 +47,7 @@ static inline uint16_t f32_to_bf16(float f) {   // round to nearest even
 // ---------------------------------------------------------------------------------------------------------
 struct ConvW { std::string wname, bname; int cin = 0, cout = 0, cout_pad = 0, ntaps = 1, w_dtype = DT_F32;
                bool nin = false; size_t w_off = 0, b_off = 0;
+               int cin_src = 0, cout_src = 0;                 // extents of the host tensor when it is zero-padded to cin / cout
                size_t wb_off = 0; bool has_wb = false; };     // slab-major copy for conv_v4_kernel (see pack_conv)
 struct GNW { std::string prefix; int C = 0; size_t g_off = 0, b_off = 0; };
 struct ResW { int idx = 0, in_ch = 0, out_ch = 0; bool up = false, down = false, has_c2 = false;
@@ -135,18 +136,20 @@ static void add_expected(use_handle* h, const std::string& name, std::vector<int
     h->expected.push_back({name, std::move(shape)});
 }
 
-static ConvW make_conv(use_handle* h, const std::string& prefix, int cin, int cout, int ntaps, int w_dtype) {
+static ConvW make_conv(use_handle* h, const std::string& prefix, int cin, int cout, int ntaps, int w_dtype,
+                       int cin_src = 0, int cout_src = 0) {
     ConvW c; c.wname = prefix + ".weight"; c.bname = prefix + ".bias"; c.cin = cin; c.cout = cout; c.ntaps = ntaps;
     c.w_dtype = w_dtype;
+    c.cin_src = cin_src ? cin_src : cin; c.cout_src = cout_src ? cout_src : cout;
     c.cout_pad = cout <= 32 ? 32 : (cout + 127) / 128 * 128;
     const int k = ntaps == 9 ? 3 : 1;
-    add_expected(h, c.wname, {cout, cin, k, k});
-    add_expected(h, c.bname, {cout});
+    add_expected(h, c.wname, {c.cout_src, c.cin_src, k, k});
+    add_expected(h, c.bname, {c.cout_src});
     return c;
 }
 static ConvW make_nin(use_handle* h, const std::string& prefix, int C, int w_dtype) {
     ConvW c; c.wname = prefix + ".W"; c.bname = prefix + ".b"; c.cin = C; c.cout = C; c.ntaps = 1; c.w_dtype = w_dtype;
-    c.nin = true; c.cout_pad = (C + 127) / 128 * 128;
+    c.nin = true; c.cout_pad = (C + 127) / 128 * 128; c.cin_src = C; c.cout_src = C;
     add_expected(h, c.wname, {C, C});
     add_expected(h, c.bname, {C});
     return c;
@@ -178,13 +181,17 @@ static ResW make_res(use_handle* h, int idx, int in_ch, int out_ch, bool up, boo
 static int build_arch(use_handle* h) {
     const use_config& c = h->cfg;
     const int nf = c.nf, L = c.n_levels, nrb = c.num_res_blocks, dt = h->act_dtype;
-    add_expected(h, "output_layer.weight", {2, 4, 1, 1});
+    // pc real input / pyramid channels in the reference tensors; stored zero-padded to 4 everywhere in the engine
+    const int pc = c.input_channels ? c.input_channels : 4;
+    add_expected(h, "output_layer.weight", {2, pc, 1, 1});
     add_expected(h, "output_layer.bias", {2});
     int m = 0;
-    add_expected(h, "all_modules.0.W", {nf}); m++;
-    add_expected(h, "all_modules.1.weight", {4 * nf, 2 * nf}); add_expected(h, "all_modules.1.bias", {4 * nf}); m++;
-    add_expected(h, "all_modules.2.weight", {4 * nf, 4 * nf}); add_expected(h, "all_modules.2.bias", {4 * nf}); m++;
-    h->conv_in = make_conv(h, "all_modules." + std::to_string(m), 4, nf, 9, DT_F32); m++;   // fp32 input always
+    add_expected(h, "all_modules.0.W", {nf}); m++;          // the Fourier projection exists even when unconditional
+    if (!c.unconditional) {
+        add_expected(h, "all_modules.1.weight", {4 * nf, 2 * nf}); add_expected(h, "all_modules.1.bias", {4 * nf}); m++;
+        add_expected(h, "all_modules.2.weight", {4 * nf, 4 * nf}); add_expected(h, "all_modules.2.bias", {4 * nf}); m++;
+    }
+    h->conv_in = make_conv(h, "all_modules." + std::to_string(m), 4, nf, 9, DT_F32, pc, 0); m++;   // fp32 input always
     std::vector<int> hs_c{nf};
     int in_ch = nf;
     for (int lvl = 0; lvl < L; ++lvl) {
@@ -196,7 +203,7 @@ static int build_arch(use_handle* h) {
         if (lvl != L - 1) {
             h->res.push_back(make_res(h, m++, in_ch, in_ch, false, true));
             CombineW cb; cb.idx = m; cb.C = in_ch;
-            add_expected(h, "all_modules." + std::to_string(m) + ".Conv_0.weight", {in_ch, 4, 1, 1});
+            add_expected(h, "all_modules." + std::to_string(m) + ".Conv_0.weight", {in_ch, pc, 1, 1});
             add_expected(h, "all_modules." + std::to_string(m) + ".Conv_0.bias", {in_ch});
             h->combines.push_back(cb); m++;
             hs_c.push_back(in_ch);
@@ -224,7 +231,7 @@ static int build_arch(use_handle* h) {
         }
         PyrW pw;
         pw.gn = make_gn(h, "all_modules." + std::to_string(m), in_ch); m++;
-        pw.conv = make_conv(h, "all_modules." + std::to_string(m), in_ch, 4, 9, dt); m++;
+        pw.conv = make_conv(h, "all_modules." + std::to_string(m), in_ch, 4, 9, dt, 0, pc); m++;
         h->pyrs.push_back(pw);
         if (lvl != 0) h->res.push_back(make_res(h, m++, in_ch, in_ch, true, false));
     }
@@ -268,10 +275,10 @@ static void pack_conv(const use_handle* h, const ConvW& w, char* blob) {
     char* dst = blob + w.w_off;
     memset(dst, 0, (size_t)w.ntaps * w.cout_pad * w.cin * es);
     for (int tap = 0; tap < w.ntaps; ++tap)
-        for (int co = 0; co < w.cout; ++co)
-            for (int ci = 0; ci < w.cin; ++ci) {
+        for (int co = 0; co < w.cout_src; ++co)
+            for (int ci = 0; ci < w.cin_src; ++ci) {
                 // reference conv weight [cout][cin][kh][kw]; NIN W is [cin][cout] (layers.py:639-650)
-                const float v = w.nin ? src[(size_t)ci * w.cout + co] : src[((size_t)co * w.cin + ci) * w.ntaps + tap];
+                const float v = w.nin ? src[(size_t)ci * w.cout + co] : src[((size_t)co * w.cin_src + ci) * w.ntaps + tap];
                 const size_t o = ((size_t)co * w.ntaps + tap) * w.cin + ci;   // [cout][tap][cin]: see use_kernels.h
                 if (w.w_dtype == DT_F32) ((float*)dst)[o] = v; else ((uint16_t*)dst)[o] = f32_to_bf16(v);
             }
@@ -280,14 +287,15 @@ static void pack_conv(const use_handle* h, const ConvW& w, char* blob) {
         char* dstb = blob + w.wb_off;
         memset(dstb, 0, (size_t)w.ntaps * w.cout_pad * w.cin * es);
         for (int tap = 0; tap < w.ntaps; ++tap)
-            for (int co = 0; co < w.cout; ++co)
-                for (int ci = 0; ci < w.cin; ++ci) {
-                    const float v = src[((size_t)co * w.cin + ci) * w.ntaps + tap];
+            for (int co = 0; co < w.cout_src; ++co)
+                for (int ci = 0; ci < w.cin_src; ++ci) {
+                    const float v = src[((size_t)co * w.cin_src + ci) * w.ntaps + tap];
                     const size_t o = (((size_t)tap * nchunks + ci / ck) * w.cout_pad + co) * ck + ci % ck;
                     if (w.w_dtype == DT_F32) ((float*)dstb)[o] = v; else ((uint16_t*)dstb)[o] = f32_to_bf16(v);
                 }
     }
-    memcpy(blob + w.b_off, bias.data(), (size_t)w.cout * 4);
+    memset(blob + w.b_off, 0, (size_t)w.cout * 4);
+    memcpy(blob + w.b_off, bias.data(), (size_t)w.cout_src * 4);
 }
 static void pack_gn(const use_handle* h, const GNW& g, char* blob) {
     memcpy(blob + g.g_off, h->host_w.at(g.prefix + ".weight").data(), (size_t)g.C * 4);
@@ -301,10 +309,19 @@ static int pack_all(use_handle* h, char* blob) {
     auto cp = [&](size_t off, const char* name) {
         const auto& v = h->host_w.at(name); memcpy(blob + off, v.data(), v.size() * 4);
     };
-    cp(h->outw_off, "output_layer.weight"); cp(h->outb_off, "output_layer.bias");
+    const int pc = h->cfg.input_channels ? h->cfg.input_channels : 4;
+    auto cp_rows = [&](size_t off, const std::string& name, int rows) {     // [rows][pc] -> [rows][4], zero-padded
+        const auto& v = h->host_w.at(name);
+        float* d = (float*)(blob + off);
+        for (int r = 0; r < rows; ++r)
+            for (int k = 0; k < 4; ++k) d[r * 4 + k] = k < pc ? v[(size_t)r * pc + k] : 0.f;
+    };
+    cp_rows(h->outw_off, "output_layer.weight", 2); cp(h->outb_off, "output_layer.bias");
     cp(h->gfp_off, "all_modules.0.W");
-    cp(h->l1w_off, "all_modules.1.weight"); cp(h->l1b_off, "all_modules.1.bias");
-    cp(h->l2w_off, "all_modules.2.weight"); cp(h->l2b_off, "all_modules.2.bias");
+    if (!h->cfg.unconditional) {
+        cp(h->l1w_off, "all_modules.1.weight"); cp(h->l1b_off, "all_modules.1.bias");
+        cp(h->l2w_off, "all_modules.2.weight"); cp(h->l2b_off, "all_modules.2.bias");
+    }
     pack_conv(h, h->conv_in, blob);
     for (const auto& r : h->res) {
         pack_gn(h, r.gn0, blob); pack_conv(h, r.c0, blob); pack_gn(h, r.gn1, blob); pack_conv(h, r.c1, blob);
@@ -322,7 +339,7 @@ static int pack_all(use_handle* h, char* blob) {
     }
     for (const auto& cb : h->combines) {
         const std::string p = "all_modules." + std::to_string(cb.idx);
-        cp(cb.w_off, (p + ".Conv_0.weight").c_str()); cp(cb.b_off, (p + ".Conv_0.bias").c_str());
+        cp_rows(cb.w_off, p + ".Conv_0.weight", cb.C); cp(cb.b_off, (p + ".Conv_0.bias").c_str());
     }
     pack_gn(h, h->attn.gn, blob);
     pack_conv(h, h->attn.q, blob); pack_conv(h, h->attn.k, blob); pack_conv(h, h->attn.v, blob); pack_conv(h, h->attn.o, blob);
@@ -410,7 +427,7 @@ struct Fwd {
     // ResnetBlockBigGANpp.forward (reference layerspp.py:282-314). `skip` = second half of the channel concat.
     Act resblock(const Act& x, const Act* skip, const ResW& r, const float* pyr = nullptr, const CombineW* cb = nullptr) {
         const float rs = 0.70710678118654752440f;   // 1/sqrt(2)
-        const float* temb = tembias + r.dense_row0;
+        const float* temb = tembias ? tembias + r.dense_row0 : nullptr;    // unconditional: no Dense_0(temb) term
         float* coef0 = gn_coef(x, skip, r.gn0);
         const int dt = h->act_dtype;
         Act hcur, xr;
@@ -442,7 +459,39 @@ struct Fwd {
         Act k = conv(x, nullptr, coef, 0, aw.k, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
         Act v = conv(x, nullptr, coef, 0, aw.v, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
         Act a = new_act(x.C, x.H, x.W, dt, false);
-        if (!h->dry) launch_attention(q.p, k.p, v.p, a.p, dt, B, x.H * x.W, x.C, s);
+        const int N = x.H * x.W;
+        const int ck = dt == DT_BF16 ? 64 : 32;
+        if (N > 512 && N % 128 == 0 && x.C % 128 == 0 && N % ck == 0) {
+            // long sequences (64x80 bottleneck of the refine generator): per batch item two implicit GEMMs on conv_kernel.
+            // The key tensor [N][C] already is a packed 1x1 weight [Cout = N][1][Cin = C]; v^T plays that part for P.V
+            const size_t es = dtype_size(dt);
+            char* sc = (char*)arena->alloc((size_t)B * N * N * es);           // scores -> probabilities, [B][N][N]
+            char* vt = (char*)arena->alloc((size_t)B * x.C * N * es);         // [B][C][N]
+            if (!h->dry) {
+                launch_transpose_nc(v.p, vt, dt, B, N, x.C, s);
+                for (int b = 0; b < B; ++b) {
+                    ConvArgs p{};
+                    p.src0 = (char*)q.p + (size_t)b * N * x.C * es; p.C0 = x.C; p.in_dtype = dt;
+                    p.w = (char*)k.p + (size_t)b * N * x.C * es; p.cout_pad = N;
+                    p.out_scale = 1.0f / std::sqrt((float)x.C);               // int(C) ** -0.5 (layerspp.py:84)
+                    p.out = sc + (size_t)b * N * N * es; p.out_dtype = dt;
+                    p.B = 1; p.H = x.H; p.W = x.W; p.Cout = N; p.ntaps = 1;
+                    launch_conv(p, s);
+                }
+                launch_softmax_rows(sc, dt, (long)B * N, N, s);
+                for (int b = 0; b < B; ++b) {
+                    ConvArgs p{};
+                    p.src0 = sc + (size_t)b * N * N * es; p.C0 = N; p.in_dtype = dt;
+                    p.w = vt + (size_t)b * x.C * N * es; p.cout_pad = x.C;
+                    p.out_scale = 1.f;
+                    p.out = (char*)a.p + (size_t)b * N * x.C * es; p.out_dtype = dt;
+                    p.B = 1; p.H = x.H; p.W = x.W; p.Cout = x.C; p.ntaps = 1;
+                    launch_conv(p, s);
+                }
+            }
+        } else if (!h->dry) {
+            launch_attention(q.p, k.p, v.p, a.p, dt, B, N, x.C, s);
+        }
         return conv(a, nullptr, nullptr, 0, aw.o, nullptr, &x, 0.70710678118654752440f, nullptr, nullptr, dt, true);
     }
 
@@ -511,7 +560,8 @@ static void run_temb(use_handle* h, const float* t, int n, float* silu_buf, floa
 
 // score = -net(cat[x, y], t): x, y device complex64
 static void run_score(use_handle* h, const float2* x, const float2* y, const float* tembias, int temb_bstride,
-                      const float* t, int t_stride, float2* out, hipStream_t s) {
+                      const float* t, int t_stride, float2* out, hipStream_t s, float sign = -1.f) {
+    if (h->cfg.no_sigma_scale) t = nullptr;                   // score_out: no division by t
     const long n_per_b = (long)h->cfg.n_freq * h->T;
     launch_pack_input(x, y, h->x4, (long)h->B * n_per_b, s);
     const float* outw = (const float*)(h->blob + h->outw_off); const float* outb = (const float*)(h->blob + h->outb_off);
@@ -519,7 +569,7 @@ static void run_score(use_handle* h, const float2* x, const float2* y, const flo
         Fwd f0{h, s, tembias, temb_bstride, t, t_stride};
         f0.B = h->B; f0.arena = &h->arena;
         Act pyr = f0.run(h->x4);
-        launch_score_out((const float*)pyr.p, t, t_stride, outw, outb, out, h->B, n_per_b, s);
+        launch_score_out((const float*)pyr.p, t, t_stride, outw, outb, out, h->B, n_per_b, sign, s);
         return;
     }
     // Sub-batches on separate streams.  The items are independent inside the network (GroupNorm is per item), so this is
@@ -535,12 +585,13 @@ static void run_score(use_handle* h, const float2* x, const float2* y, const flo
             (void)hipStreamWaitEvent(si, h->ev_fork, 0);
             (void)hipStreamWaitEvent(si, h->ev_stagger[i - 1], 0);
         }
-        Fwd f{h, si, tembias + (size_t)b0 * temb_bstride, temb_bstride, t + (size_t)b0 * t_stride, t_stride};
+        Fwd f{h, si, tembias ? tembias + (size_t)b0 * temb_bstride : nullptr, temb_bstride,
+              t ? t + (size_t)b0 * t_stride : nullptr, t_stride};
         f.B = h->sub_B[i]; f.arena = i ? &h->sub_arena[i] : &h->arena; f.primary = i == 0;
         if (overlap && i + 1 < h->nsub) f.ev_stagger = h->ev_stagger[i];
         Act pyr = f.run(h->x4 + (size_t)b0 * n_per_b * 4);
-        launch_score_out((const float*)pyr.p, t + (size_t)b0 * t_stride, t_stride, outw, outb, out + (size_t)b0 * n_per_b,
-                         h->sub_B[i], n_per_b, si);
+        launch_score_out((const float*)pyr.p, t ? t + (size_t)b0 * t_stride : nullptr, t_stride, outw, outb,
+                         out + (size_t)b0 * n_per_b, h->sub_B[i], n_per_b, sign, si);
         if (overlap && i) (void)hipEventRecord(h->ev_join[i], si);
         b0 += h->sub_B[i];
     }
@@ -667,6 +718,8 @@ int use_create(const use_config* cfg, int device, use_handle** out) {
     if (cfg->n_freq % (1 << (cfg->n_levels - 1)) != 0)
         return fail(USE_E_INVALID, "n_freq=%d is not divisible by 2^(levels-1)", cfg->n_freq);
     if (cfg->precision != USE_PREC_FP32 && cfg->precision != USE_PREC_BF16) return fail(USE_E_INVALID, "bad precision");
+    if (cfg->input_channels != 0 && cfg->input_channels != 2 && cfg->input_channels != 4)
+        return fail(USE_E_INVALID, "input_channels must be 4 (x and y) or 2 (y alone), got %d", cfg->input_channels);
     use_handle* h = new use_handle();
     h->cfg = *cfg; h->device = device;
     h->act_dtype = cfg->precision == USE_PREC_BF16 ? DT_BF16 : DT_F32;
@@ -831,14 +884,25 @@ static int check_ready(use_handle* h) {
     return USE_OK;
 }
 
-int use_score(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream) {
+// one network evaluation; sign -1: the score (use_score), +1: the raw backbone output (use_forward)
+static int eval_net(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream, float sign) {
     int rc = check_ready(h); if (rc) return rc;
-    if (!x || !y || !t || !out) return fail(USE_E_INVALID, "null tensor");
+    const use_config& c = h->cfg;
+    const bool two_ch = c.input_channels == 2;
+    if (!x || !out) return fail(USE_E_INVALID, "null tensor");
+    if (two_ch ? y != nullptr : y == nullptr) return fail(USE_E_INVALID, two_ch ? "a 2-channel network takes x alone (y must be null)" : "null tensor");
+    if (!t && (!c.unconditional || !c.no_sigma_scale)) return fail(USE_E_INVALID, "this network needs the time t");
     hipStream_t s = (hipStream_t)stream;
-    run_temb(h, t, h->B, h->silu_temb, h->tembias, s);
-    run_score(h, (const float2*)x, (const float2*)y, h->tembias, h->dense_rows, t, 1, (float2*)out, s);
+    if (!c.unconditional) run_temb(h, t, h->B, h->silu_temb, h->tembias, s);
+    run_score(h, (const float2*)x, (const float2*)y, c.unconditional ? nullptr : h->tembias, h->dense_rows, t, 1, (float2*)out, s, sign);
     HIPCHK(hipGetLastError());
     return USE_OK;
+}
+int use_score(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream) {
+    return eval_net(h, x, y, t, out, stream, -1.f);
+}
+int use_forward(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream) {
+    return eval_net(h, x, y, t, out, stream, +1.f);
 }
 
 int use_profile_score(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream,
@@ -884,6 +948,8 @@ int use_timesteps(int N, float t_eps, float* out) {
 int use_set_sampler(use_handle* h, const use_sampler_config* sc) {
     int rc = check_ready(h); if (rc) return rc;
     if (!sc || sc->N < 1) return fail(USE_E_INVALID, "sampler needs N >= 1");
+    if (h->cfg.unconditional || h->cfg.input_channels == 2 || h->cfg.no_sigma_scale)
+        return fail(USE_E_STATE, "the reverse-SDE sampler needs the conditional 4-channel score network");
     if (sc->predictor < 0 || sc->predictor > 2 || sc->corrector < 0 || sc->corrector > 2) return fail(USE_E_INVALID, "unknown predictor/corrector id");
     if (sc->corrector != USE_CORR_NONE && sc->corrector_steps < 0) return fail(USE_E_INVALID, "negative corrector_steps");
     HIPCHK(hipSetDevice(h->device));

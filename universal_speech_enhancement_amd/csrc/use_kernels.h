@@ -88,9 +88,13 @@ void launch_temb_dense(const float* silu_temb, const float* W, const float* bias
 void launch_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int N, int C,
                       hipStream_t s);
 
-// net = conv1x1_{4->2}(pyr / t[b]); score = -net  (complex64 out)
+// helpers of the long-sequence attention path (two implicit GEMMs on conv_kernel, see Fwd::attention)
+void launch_softmax_rows(void* x, int dtype, long rows, int cols, hipStream_t s);            // in place, over the last axis
+void launch_transpose_nc(const void* in, void* out, int dtype, int B, int N, int C, hipStream_t s);   // [B][N][C] -> [B][C][N]
+
+// net = conv1x1_{4->2}(pyr / t[b]) (t == null: no division); out = sign * net  (complex64 out; sign -1: the score)
 void launch_score_out(const float* pyr, const float* t, int t_stride, const float* w, const float* bias,
-                      float2* score, int B, long pix_per_b, hipStream_t s);
+                      float2* score, int B, long pix_per_b, float sign, hipStream_t s);
 
 // ---- SDE updates (complex64 as float2, fp32 arithmetic) ----
 struct RngRef { const unsigned long long* state; unsigned draw; };  // state[0]=seed, state[1]=draw base

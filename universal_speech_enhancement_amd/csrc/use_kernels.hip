@@ -878,7 +878,9 @@ void launch_fir_down2(const void* src, int dtype, const float* coef, int act, vo
 __global__ __launch_bounds__(256) void pack_input_kernel(const float2* __restrict__ x, const float2* __restrict__ y,
                                                          float4* __restrict__ x4, long npix) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
-        const float2 a = x[i], c = y[i];
+        const float2 a = x[i];
+        // y == null: a 2-channel network (NCSNpp(discriminative=True)); the two padding channels meet zero weights
+        const float2 c = y ? y[i] : make_float2(0.5f, 0.5f);
         x4[i] = make_float4(2.f * a.x - 1.f, 2.f * a.y - 1.f, 2.f * c.x - 1.f, 2.f * c.y - 1.f);
     }
 }
@@ -989,30 +991,75 @@ void launch_attention(const void* q, const void* k, const void* v, void* out, in
                            (const __bf16*)k, (const __bf16*)v, (__bf16*)out, N, C);
 }
 
+// Long token sequences (the 64x80 bottleneck of the LSGAN refine generator: N = 5120) run the attention core as two
+// implicit GEMMs on conv_kernel -- scores = conv1x1(q; weights = k), out = conv1x1(softmax(scores); weights = v^T), the
+// [N][C] key tensor already being the packed [Cout][1][Cin] weight layout -- with these two helpers in between.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ x, int cols) {
+    __shared__ float red[4];
+    T* row = x + (size_t)blockIdx.x * cols;
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (int j = tid; j < cols; j += 256) mx = fmaxf(mx, to_f(row[j]));
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = tid; j < cols; j += 256) sum += expf(to_f(row[j]) - mx);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+    for (int j = tid; j < cols; j += 256) row[j] = from_f<T>(expf(to_f(row[j]) - mx) * inv);
+}
+void launch_softmax_rows(void* x, int dtype, long rows, int cols, hipStream_t s) {
+    if (dtype == DT_F32) hipLaunchKernelGGL((softmax_rows_kernel<float>), dim3((unsigned)rows), dim3(256), 0, s, (float*)x, cols);
+    else                 hipLaunchKernelGGL((softmax_rows_kernel<__bf16>), dim3((unsigned)rows), dim3(256), 0, s, (__bf16*)x, cols);
+}
+// out[b][c][n] = in[b][n][c]  (32x32 tiles through LDS)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_nc_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int C) {
+    __shared__ T tile[32][33];
+    const int b = blockIdx.z, n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (n0 + r < N && c0 + tx < C) tile[r][tx] = in[((size_t)b * N + n0 + r) * C + c0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (c0 + r < C && n0 + tx < N) out[((size_t)b * C + c0 + r) * N + n0 + tx] = tile[tx][r];
+}
+void launch_transpose_nc(const void* in, void* out, int dtype, int B, int N, int C, hipStream_t s) {
+    dim3 grid((N + 31) / 32, (C + 31) / 32, B);
+    if (dtype == DT_F32) hipLaunchKernelGGL((transpose_nc_kernel<float>), grid, dim3(256), 0, s, (const float*)in, (float*)out, N, C);
+    else                 hipLaunchKernelGGL((transpose_nc_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)in, (__bf16*)out, N, C);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Output layer + SDE updates
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void score_out_kernel(const float4* __restrict__ pyr, const float* __restrict__ t,
                                                         int t_stride, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float2* __restrict__ score,
-                                                        long pix_per_b) {
+                                                        long pix_per_b, float sign) {
     const int b = blockIdx.y;
-    const float tv = t[(size_t)b * t_stride];
+    const float tv = t ? t[(size_t)b * t_stride] : 1.0f;      // t == null: scale_by_sigma=False
     const float w00 = w[0], w01 = w[1], w02 = w[2], w03 = w[3], w10 = w[4], w11 = w[5], w12 = w[6], w13 = w[7];
     const float b0 = bias[0], b1 = bias[1];
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pix_per_b; i += (long)gridDim.x * 256) {
         float4 h = pyr[(size_t)b * pix_per_b + i];
-        h.x /= tv; h.y /= tv; h.z /= tv; h.w /= tv;              // h / used_sigmas (ncsnpp.py:492-494)
+        if (t) { h.x /= tv; h.y /= tv; h.z /= tv; h.w /= tv; }   // h / used_sigmas (ncsnpp.py:492-494)
         const float re = b0 + w00 * h.x + w01 * h.y + w02 * h.z + w03 * h.w;
         const float im = b1 + w10 * h.x + w11 * h.y + w12 * h.z + w13 * h.w;
-        score[(size_t)b * pix_per_b + i] = make_float2(-re, -im);  // score = -score_net(...) (model_wrapper.py:137)
+        score[(size_t)b * pix_per_b + i] = make_float2(sign * re, sign * im);  // sign -1: score = -score_net(...) (model_wrapper.py:137)
     }
 }
 void launch_score_out(const float* pyr, const float* t, int t_stride, const float* w, const float* bias,
-                      float2* score, int B, long pix_per_b, hipStream_t s) {
+                      float2* score, int B, long pix_per_b, float sign, hipStream_t s) {
     int bx = (int)((pix_per_b + 255) / 256); if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(score_out_kernel, dim3(bx, B), dim3(256), 0, s, (const float4*)pyr, t, t_stride, w, bias, score,
-                       pix_per_b);
+                       pix_per_b, sign);
 }
 
 // Philox4x32-10 counter RNG -> complex normal with E|z|^2 = 1 (torch.randn_like(complex) law).

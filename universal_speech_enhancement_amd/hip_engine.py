@@ -39,7 +39,8 @@ class HipScoreEngine:
     """One handle per (process, device).  Not re-entrant."""
 
     def __init__(self, nf=128, ch_mult: Sequence[int] = (1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, n_freq=512,
-                 precision="bf16", device: Optional[int] = None, theta=1.5, sigma_min=0.05, sigma_max=0.5):
+                 precision="bf16", device: Optional[int] = None, theta=1.5, sigma_min=0.05, sigma_max=0.5,
+                 input_channels=4, conditional=True, scale_by_sigma=True):
         if precision not in _lib.PREC:
             raise ValueError(f"precision must be one of {list(_lib.PREC)}, got {precision!r}")
         self.L = _lib.lib()
@@ -50,6 +51,8 @@ class HipScoreEngine:
             cfg.ch_mult[i] = int(m)
         cfg.precision = _lib.PREC[precision]
         cfg.theta, cfg.sigma_min, cfg.sigma_max = theta, sigma_min, sigma_max
+        cfg.input_channels, cfg.unconditional, cfg.no_sigma_scale = int(input_channels), int(not conditional), int(not scale_by_sigma)
+        self.input_channels, self.conditional = int(input_channels), bool(conditional)
         self.cfg, self.precision, self.n_freq = cfg, precision, n_freq
         h = C.c_void_p()
         check(self.L.use_create(C.byref(cfg), self.device, C.byref(h)), "use_create")
@@ -140,6 +143,22 @@ class HipScoreEngine:
             raise ValueError(f"t must have {B} elements")
         out = torch.empty_like(x)
         check(self.L.use_score(self.h, x.data_ptr(), y.data_ptr(), t.data_ptr(), out.data_ptr(), _stream_ptr(x.device)), "use_score")
+        return out
+
+    def forward(self, x: torch.Tensor, y: Optional[torch.Tensor] = None, t: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Raw backbone output ``NCSNpp.forward(cat[x, y], t)`` (``use_forward``).  ``y`` is None for a 2-channel
+        (discriminative) network, ``t`` is None for an unconditional one."""
+        x = _require_cuda_c64("x", x)
+        if y is not None:
+            y = _require_cuda_c64("y", y, x.shape)
+        self.plan(x.shape[0], x.shape[3])
+        if t is not None:
+            t = t.to(device=x.device, dtype=torch.float32).contiguous()
+            if t.shape != (x.shape[0],):
+                raise ValueError(f"t must have shape [{x.shape[0]}]")
+        out = torch.empty_like(x)
+        check(self.L.use_forward(self.h, x.data_ptr(), None if y is None else y.data_ptr(), None if t is None else t.data_ptr(),
+                                 out.data_ptr(), _stream_ptr(x.device)), "use_forward")
         return out
 
     def profile_score(self, x, y, t):

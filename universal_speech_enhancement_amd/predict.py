@@ -90,9 +90,10 @@ def predict(cfg: dict):
     if cfg.get("ckpt_path"):
         model.load_lightning_checkpoint(cfg["ckpt_path"])
     elif cfg.get("random_init_seed") is not None:
-        from .testing.weights import LARGE, make_state_dict
-        sd = make_state_dict(int(cfg["random_init_seed"]), **LARGE)
-        model.Score.score_net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        from .testing.weights import LARGE, REFINE, make_state_dict
+        refine = hasattr(model, "G")                          # model=LSGAN: the refine-stage generator
+        sd = make_state_dict(int(cfg["random_init_seed"]), **(REFINE if refine else LARGE))
+        (model.G.net if refine else model.Score.score_net).load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     else:
         raise SystemExit("ckpt_path is required (or random_init_seed=<int> for a dry run)")
     n = 0

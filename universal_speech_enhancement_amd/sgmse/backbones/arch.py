@@ -42,8 +42,8 @@ def ncsnpp_param_shapes(
         nonlocal idx
         add_plain("GroupNorm_0.weight", (in_ch,)); add_plain("GroupNorm_0.bias", (in_ch,))
         add_plain("Conv_0.weight", (out_ch, in_ch, 3, 3)); add_plain("Conv_0.bias", (out_ch,))
-        if conditional:
-            add_plain("Dense_0.weight", (out_ch, temb_dim)); add_plain("Dense_0.bias", (out_ch,))
+        # Dense_0 exists even when the network is unconditional (temb_dim is always passed, ncsnpp.py:160-171)
+        add_plain("Dense_0.weight", (out_ch, temb_dim)); add_plain("Dense_0.bias", (out_ch,))
         add_plain("GroupNorm_1.weight", (out_ch,)); add_plain("GroupNorm_1.bias", (out_ch,))
         add_plain("Conv_1.weight", (out_ch, out_ch, 3, 3)); add_plain("Conv_1.bias", (out_ch,))
         if in_ch != out_ch or resample:

@@ -40,21 +40,27 @@ class NCSNpp(nn.Module):
     supports_hip = True
 
     def __init__(self, nf=128, ch_mult: Sequence[int] = (1, 2, 2, 2), num_res_blocks=1, input_channels=4,
-                 fourier_scale=16, init_scale=0.0, image_size=256, precision="bf16", n_freq=None, **unsupported):
+                 fourier_scale=16, init_scale=0.0, image_size=256, precision="bf16", n_freq=None,
+                 scale_by_sigma=True, conditional=True, discriminative=False, **unsupported):
         super().__init__()
-        fixed = dict(scale_by_sigma=True, nonlinearity="swish", attn_resolutions=(0,), resamp_with_conv=True,
-                     conditional=True, fir=True, fir_kernel=[1, 3, 3, 1], skip_rescale=True, resblock_type="biggan",
+        fixed = dict(nonlinearity="swish", attn_resolutions=(0,), resamp_with_conv=True,
+                     fir=True, fir_kernel=[1, 3, 3, 1], skip_rescale=True, resblock_type="biggan",
                      progressive="output_skip", progressive_input="input_skip", progressive_combine="sum",
-                     embedding_type="fourier", spatial_channels=1, dropout=0.0, centered=False, discriminative=False)
+                     embedding_type="fourier", spatial_channels=1, dropout=0.0, centered=False)
         for k, v in unsupported.items():
             if k in fixed and (list(v) if isinstance(v, (list, tuple)) else v) != (list(fixed[k]) if isinstance(fixed[k], (list, tuple)) else fixed[k]):
                 raise NotImplementedError(f"NCSNpp(HIP): option {k}={v!r} is outside the predict-path configuration ({fixed[k]!r})")
-        if input_channels != 4:
-            raise NotImplementedError("NCSNpp(HIP): only condition='noisy' (input_channels=4) is implemented")
+        self.discriminative = bool(discriminative)
+        if self.discriminative:      # reference ncsnpp.py:86-92: options that make no sense for a discriminative model
+            conditional, scale_by_sigma, input_channels = False, False, 2
+        if input_channels not in (2, 4):
+            raise NotImplementedError("NCSNpp(HIP): input_channels must be 4 (condition='noisy') or 2 (discriminative)")
+        self.conditional, self.scale_by_sigma = bool(conditional), bool(scale_by_sigma)
         self.nf, self.ch_mult, self.num_res_blocks = nf, tuple(ch_mult), num_res_blocks
         self.input_channels, self.precision, self.n_freq = input_channels, precision, n_freq
         gen = torch.Generator().manual_seed(torch.initial_seed() & 0x7FFFFFFF)
-        shapes = ncsnpp_param_shapes(nf=nf, ch_mult=ch_mult, num_res_blocks=num_res_blocks, input_channels=input_channels)
+        shapes = ncsnpp_param_shapes(nf=nf, ch_mult=ch_mult, num_res_blocks=num_res_blocks, input_channels=input_channels,
+                                     conditional=self.conditional)
         self.output_layer = _Holder()
         self.all_modules = nn.ModuleList()
         zero_init = ("Conv_1.weight", "NIN_3.W")          # init_scale=0 layers (reference layerspp.py:74,273)
@@ -93,7 +99,9 @@ class NCSNpp(nn.Module):
         if self._engine is None or self._engine.n_freq != n_freq:
             self._engine = HipScoreEngine(nf=self.nf, ch_mult=self.ch_mult, num_res_blocks=self.num_res_blocks,
                                           n_freq=n_freq, precision=self.precision,
-                                          device=None if device is None else torch.device(device).index)
+                                          device=None if device is None else torch.device(device).index,
+                                          input_channels=self.input_channels, conditional=self.conditional,
+                                          scale_by_sigma=self.scale_by_sigma)
             self._engine_dirty = True
         if self._engine_dirty:
             self._engine.load_state_dict(self.state_dict())
@@ -104,15 +112,20 @@ class NCSNpp(nn.Module):
         """Call after modifying parameters in place (``load_state_dict`` is tracked automatically)."""
         self._engine_dirty = True
 
-    def forward(self, x: torch.Tensor, time_cond: torch.Tensor) -> torch.Tensor:
-        if x.dim() != 4 or x.shape[1] != 2:
-            raise ValueError("expected complex input [B, 2, F, T'] = cat([x_t, Y], dim=1)")
+    def forward(self, x: torch.Tensor, time_cond: torch.Tensor = None) -> torch.Tensor:
+        nin = self.input_channels // 2
+        if x.dim() != 4 or x.shape[1] != nin:
+            raise ValueError("expected complex input [B, 2, F, T'] = cat([x_t, Y], dim=1)" if nin == 2 else
+                             "expected complex input [B, 1, F, T'] (discriminative network)")
         if not x.is_cuda:
             from ...hip_engine import UseHipError
-            raise UseHipError("NCSN++ (HIP) needs CUDA/ROCm tensors: the score network has no CPU implementation")
+            raise UseHipError("NCSN++ (HIP) needs CUDA/ROCm tensors: the network has no CPU implementation")
+        if self.conditional and time_cond is None:
+            raise ValueError("a conditional NCSN++ needs time_cond")
         eng = self.engine(x.shape[2], x.device)
-        # the library returns the score (-network output); the backbone contract is the raw output
-        return -eng.score(x[:, 0:1], x[:, 1:2], time_cond)
+        if nin == 1:
+            return eng.forward(x, None, time_cond if (self.conditional or self.scale_by_sigma) else None)
+        return eng.forward(x[:, 0:1], x[:, 1:2], time_cond)
 
 
 @BackboneRegistry.register("ncsnpplarge")

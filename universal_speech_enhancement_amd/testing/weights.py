@@ -103,3 +103,5 @@ def weights_checksum(sd: Dict[str, np.ndarray]) -> str:
 
 
 LARGE = dict(nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, input_channels=4)
+# NCSNpp(discriminative=True): the generator of the LSGAN refine stage (reference ncsnpp.py:42-69 defaults + 86-92)
+REFINE = dict(nf=128, ch_mult=(1, 2, 2, 2), num_res_blocks=1, input_channels=2, conditional=False)
