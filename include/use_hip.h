@@ -82,6 +82,13 @@ int use_commit_weights(use_handle* h);
  * rank 0 commits, the others call use_alloc_weight_blob, all ranks broadcast [ptr, ptr+bytes). */
 int use_alloc_weight_blob(use_handle* h);
 int use_weight_blob(use_handle* h, void** dev_ptr, size_t* bytes);
+/* Packed weight file: a versioned header (architecture, precision, blob layout version, crc32) + the device blob, so that a
+ * deployment starts from one read instead of a Lightning checkpoint (which replaces `torch.load` + `load_state_dict`,
+ * predict.py:79).  use_save_weight_blob works after use_set_weight of every tensor (packs on the host: no GPU needed) or
+ * after a commit / load; use_load_weight_blob replaces use_set_weight x N + use_commit_weights and refuses files packed
+ * for another configuration, precision or layout version. */
+int use_save_weight_blob(use_handle* h, const char* path);
+int use_load_weight_blob(use_handle* h, const char* path);
 int use_num_expected_weights(use_handle* h);
 int use_expected_weight(use_handle* h, int index, const char** name, int64_t* shape4, int* ndim);
 

@@ -183,3 +183,27 @@ def test_predict_config_composition_and_loader(tmp_path):
     assert "G.net.all_modules.2.Dense_0.weight" in keys        # present (and unused) in the unconditional network too
     with pytest.raises(NotImplementedError):
         gan.G({"clean": torch.zeros(1, 10), "perturbed": torch.zeros(1, 10)})
+
+
+def test_packed_weight_file_is_written_on_the_host(tmp_path):
+    """Lightning-checkpoint keys -> packed weight file, no GPU involved; header fields and failure modes."""
+    import struct
+    from universal_speech_enhancement_amd.hip_engine import HipScoreEngine
+    from universal_speech_enhancement_amd.pack_checkpoint import pack
+    from universal_speech_enhancement_amd.testing import weights as tw
+    sd = {"G.net." + k: torch.from_numpy(v) for k, v in tw.make_state_dict(4321, **tw.REFINE).items()}
+    out = str(tmp_path / "refine.usehip")
+    pack(sd, out, "LSGAN", "bf16")
+    raw = open(out, "rb").read()
+    assert raw[:8] == b"USEHIPWB"
+    header_bytes, layout, nf, n_levels = struct.unpack_from("<IIii", raw, 8)
+    assert nf == 128 and n_levels == 4 and layout >= 3 and len(raw) > header_bytes + 50_000_000
+    blob_bytes = struct.unpack_from("<Q", raw, header_bytes - 8)[0]
+    assert len(raw) == header_bytes + blob_bytes
+    with pytest.raises(KeyError):
+        pack({"unrelated": torch.zeros(1)}, out, "LSGAN", "bf16")
+    e = HipScoreEngine(precision="bf16", device=0)            # nothing set yet: nothing to save
+    with pytest.raises(_lib.UseHipError):
+        e.save_weight_blob(str(tmp_path / "empty.usehip"))
+    e.close()
+

@@ -118,6 +118,37 @@ def test_refine_generator_long_sequence_attention(prec, tol):
     assert _relmax(out, ref) < tol, _relmax(out, ref)
 
 
+def test_packed_weight_file_round_trip(tmp_path, golden_dir, engines, sd_np):
+    """an engine started from a packed weight file gives the same score as one fed the state dict; files for
+    another precision / configuration or with a damaged payload are refused."""
+    from universal_speech_enhancement_amd.hip_engine import HipScoreEngine
+    g = dict(np.load(os.path.join(golden_dir, "forward_large.npz")))
+    x = torch.from_numpy(g["x"]).cuda()
+    t = torch.from_numpy(g["t_a"]).cuda()
+    path = str(tmp_path / "large_bf16.usehip")
+    engines["bf16"].save_weight_blob(path)                    # from the committed device blob
+    e = HipScoreEngine(precision="bf16")
+    e.load_weight_blob(path)
+    a = engines["bf16"].score(x[:, 0:1].contiguous(), x[:, 1:2].contiguous(), t)
+    b = e.score(x[:, 0:1].contiguous(), x[:, 1:2].contiguous(), t)
+    assert torch.equal(a, b)
+    e.close()
+    e32 = HipScoreEngine(precision="fp32")
+    with pytest.raises(UseHipError):
+        e32.load_weight_blob(path)                            # packed for bf16
+    e32.close()
+    raw = bytearray(open(path, "rb").read())
+    raw[len(raw) // 2] ^= 0xFF
+    bad = str(tmp_path / "bad.usehip")
+    open(bad, "wb").write(bytes(raw))
+    e2 = HipScoreEngine(precision="bf16")
+    with pytest.raises(UseHipError):
+        e2.load_weight_blob(bad)                              # checksum
+    with pytest.raises(UseHipError):
+        e2.load_weight_blob(str(tmp_path / "missing.usehip"))
+    e2.close()
+
+
 def test_odd_widths_at_the_bottom_of_the_unet_fp32(engines, sd_np):
     """T' = 192 = 3 x 64: feature-map widths 192, 96, 48, 24, 12, 6, 3 -- partially filled tiles in every conv kernel
     (conv_v4 at 512x192, conv_v2 at 48 / 24 columns, conv_kernel at 12 / 6 / 3) and odd FIR sizes.  Against the CPU oracle."""

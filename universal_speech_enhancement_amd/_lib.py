@@ -47,6 +47,8 @@ SYMBOLS = {
     "use_commit_weights": (_i, [_vp]),
     "use_alloc_weight_blob": (_i, [_vp]),
     "use_weight_blob": (_i, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "use_save_weight_blob": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "use_load_weight_blob": (C.c_int, [C.c_void_p, C.c_char_p]),
     "use_num_expected_weights": (_i, [_vp]),
     "use_expected_weight": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i)]),
     "use_plan": (_i, [_vp, _i, _i]),

@@ -801,6 +801,88 @@ int use_commit_weights(use_handle* h) {
     return USE_OK;
 }
 
+// ---- packed weight file: header + the device blob, so that a deployment starts without a state dict ------
+// The blob layout is private to a library build: BLOB_LAYOUT is bumped whenever pack_all / the blob offsets change.
+namespace {
+constexpr uint32_t BLOB_LAYOUT = 3;          // 3: second, slab-major copy of the 3x3 / shortcut weights (conv_v4_kernel)
+struct BlobHeader {
+    char magic[8];                           // "USEHIPWB"
+    uint32_t header_bytes, layout;
+    int32_t nf, n_levels, ch_mult[8], num_res_blocks, precision, input_channels, unconditional, no_sigma_scale;
+    uint32_t crc32, reserved;
+    uint64_t blob_bytes;
+};
+uint32_t crc32_of(const unsigned char* p, size_t n) {
+    static uint32_t table[256]; static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = c & 1 ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        init = true;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+BlobHeader make_header(const use_handle* h) {
+    BlobHeader hd{};
+    memcpy(hd.magic, "USEHIPWB", 8);
+    hd.header_bytes = sizeof(BlobHeader); hd.layout = BLOB_LAYOUT;
+    const use_config& c = h->cfg;
+    hd.nf = c.nf; hd.n_levels = c.n_levels; for (int i = 0; i < 8; ++i) hd.ch_mult[i] = i < c.n_levels ? c.ch_mult[i] : 0;
+    hd.num_res_blocks = c.num_res_blocks; hd.precision = c.precision;
+    hd.input_channels = c.input_channels ? c.input_channels : 4; hd.unconditional = c.unconditional != 0; hd.no_sigma_scale = c.no_sigma_scale != 0;
+    hd.blob_bytes = h->blob_bytes;
+    return hd;
+}
+}  // namespace
+
+int use_save_weight_blob(use_handle* h, const char* path) {
+    if (!h || !path) return fail(USE_E_INVALID, "null argument");
+    std::vector<char> host(h->blob_bytes, 0);
+    if (!h->host_w.empty()) {                                 // weights set but not committed: pack on the host, no GPU needed
+        int rc = pack_all(h, host.data());
+        if (rc) return rc;
+    } else if (h->blob && h->weights_ready) {
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipMemcpy(host.data(), h->blob, h->blob_bytes, hipMemcpyDeviceToHost));
+    } else {
+        return fail(USE_E_STATE, "no weights to save (use_set_weight every tensor, or commit / load first)");
+    }
+    BlobHeader hd = make_header(h);
+    hd.crc32 = crc32_of((const unsigned char*)host.data(), host.size());
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(USE_E_INVALID, "cannot open '%s' for writing", path);
+    const bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && fwrite(host.data(), 1, host.size(), f) == host.size();
+    if (fclose(f) != 0 || !ok) return fail(USE_E_INVALID, "short write to '%s'", path);
+    return USE_OK;
+}
+
+int use_load_weight_blob(use_handle* h, const char* path) {
+    if (!h || !path) return fail(USE_E_INVALID, "null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(USE_E_INVALID, "cannot open '%s'", path);
+    BlobHeader hd{}, want = make_header(h);
+    std::vector<char> host(h->blob_bytes);
+    if (fread(&hd, sizeof hd, 1, f) != 1) { fclose(f); return fail(USE_E_INVALID, "'%s' is truncated", path); }
+    if (memcmp(hd.magic, want.magic, 8) != 0 || hd.header_bytes != sizeof hd) { fclose(f); return fail(USE_E_INVALID, "'%s' is not a use_hip weight file", path); }
+    if (hd.layout != want.layout) { fclose(f); return fail(USE_E_INVALID, "'%s' has blob layout %u, this build reads %u: re-pack the checkpoint", path, hd.layout, want.layout); }
+    {
+        BlobHeader a = hd; a.crc32 = 0;                       // everything but the checksum describes the network
+        if (memcmp(&a, &want, sizeof a) != 0) { fclose(f); return fail(USE_E_INVALID, "'%s' was packed for a different network configuration / precision", path); }
+    }
+    const bool ok = fread(host.data(), 1, host.size(), f) == host.size();
+    fclose(f);
+    if (!ok) return fail(USE_E_INVALID, "'%s' is truncated", path);
+    if (crc32_of((const unsigned char*)host.data(), host.size()) != hd.crc32) return fail(USE_E_INVALID, "'%s': checksum mismatch", path);
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->blob) HIPCHK(hipMalloc((void**)&h->blob, h->blob_bytes));
+    HIPCHK(hipMemcpy(h->blob, host.data(), h->blob_bytes, hipMemcpyHostToDevice));
+    h->host_w.clear();
+    h->weights_ready = true;
+    h->sampler_set = false;
+    drop_graphs(h);
+    return USE_OK;
+}
+
 int use_weight_blob(use_handle* h, void** dev_ptr, size_t* bytes) {
     if (!h) return fail(USE_E_INVALID, "null handle");
     if (dev_ptr) *dev_ptr = h->blob;

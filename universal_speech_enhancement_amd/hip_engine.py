@@ -6,6 +6,7 @@ PyTorch is plumbing only here (device memory, streams); all arithmetic on the pa
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -73,6 +74,15 @@ class HipScoreEngine:
             pass
 
     # ---- weights ------------------------------------------------------------------------------------
+    def save_weight_blob(self, path: str) -> None:
+        """Packed weight file (``use_save_weight_blob``): after ``set_weights`` of every tensor (no GPU needed) or a commit."""
+        check(self.L.use_save_weight_blob(self.h, os.fsencode(path)), "use_save_weight_blob")
+
+    def load_weight_blob(self, path: str) -> None:
+        """Start from a packed weight file instead of a state dict (``use_load_weight_blob``)."""
+        check(self.L.use_load_weight_blob(self.h, os.fsencode(path)), "use_load_weight_blob")
+        self.weights_ready = True
+
     def expected_weights(self) -> Dict[str, tuple]:
         out = {}
         n = check(self.L.use_num_expected_weights(self.h))
@@ -84,6 +94,13 @@ class HipScoreEngine:
 
     def load_state_dict(self, sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str = ""):
         """Upload weights given under the reference's state-dict keys (optionally behind ``prefix``)."""
+        self.set_weights(sd, prefix)
+        check(self.L.use_commit_weights(self.h), "use_commit_weights")
+        self.weights_ready = True
+        self.sampler_key = None
+
+    def set_weights(self, sd: Dict[str, "np.ndarray | torch.Tensor"], prefix: str = ""):
+        """``use_set_weight`` for every tensor, without committing to the device (enough for ``save_weight_blob``)."""
         for name in self.expected_weights():
             key = prefix + name
             if key not in sd:
@@ -92,9 +109,6 @@ class HipScoreEngine:
             a = v.detach().cpu().float().contiguous().numpy() if isinstance(v, torch.Tensor) else np.ascontiguousarray(v, dtype=np.float32)
             shape = (C.c_int64 * a.ndim)(*a.shape)
             check(self.L.use_set_weight(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim), f"use_set_weight({name})")
-        check(self.L.use_commit_weights(self.h), "use_commit_weights")
-        self.weights_ready = True
-        self.sampler_key = None
 
     def weight_blob(self) -> torch.Tensor:
         """uint8 CUDA view of the packed device blob (for a one-time RCCL broadcast from rank 0)."""

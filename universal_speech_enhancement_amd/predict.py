@@ -87,7 +87,10 @@ def predict(cfg: dict):
     torch.cuda.set_device(local)
     data = instantiate(cfg["data"], rank=rank, world_size=world)
     model = instantiate(cfg["model"])
-    if cfg.get("ckpt_path"):
+    if cfg.get("ckpt_path") and str(cfg["ckpt_path"]).endswith(".usehip"):   # packed weight file (pack_checkpoint)
+        net = model.G.net if hasattr(model, "G") else model.Score.score_net
+        net.load_weight_file(cfg["ckpt_path"], device=torch.device("cuda", local))
+    elif cfg.get("ckpt_path"):
         model.load_lightning_checkpoint(cfg["ckpt_path"])
     elif cfg.get("random_init_seed") is not None:
         from .testing.weights import LARGE, REFINE, make_state_dict

@@ -108,6 +108,17 @@ class NCSNpp(nn.Module):
             self._engine_dirty = False
         return self._engine
 
+    def load_weight_file(self, path: str, n_freq: int = 512, device=None):
+        """Start from a packed weight file (``pack_checkpoint``; ``use_load_weight_blob``) instead of a state dict: the
+        module's own parameters are left untouched and no longer consulted."""
+        from ...hip_engine import HipScoreEngine
+        self._engine = HipScoreEngine(nf=self.nf, ch_mult=self.ch_mult, num_res_blocks=self.num_res_blocks, n_freq=n_freq,
+                                      precision=self.precision, device=None if device is None else torch.device(device).index,
+                                      input_channels=self.input_channels, conditional=self.conditional,
+                                      scale_by_sigma=self.scale_by_sigma)
+        self._engine.load_weight_blob(path)
+        self._engine_dirty = False
+
     def refresh_weights(self):
         """Call after modifying parameters in place (``load_state_dict`` is tracked automatically)."""
         self._engine_dirty = True
