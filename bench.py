@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--subbatch", type=int, default=None, help="sub-batches per score evaluation (library default if unset)")
+    ap.add_argument("--stagger-level", type=int, default=None)
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the timed sampler steps; run only the per-launch measurement of the dominant kernel (for "
                          "`rocprofv3 --kernel-trace --stats -- python bench.py --roofline-only`, see profiles/README.md)")
@@ -113,6 +115,11 @@ def main():
     from universal_speech_enhancement_amd.testing import noise as tn
     from universal_speech_enhancement_amd.testing import weights as tw
 
+    from universal_speech_enhancement_amd.hip_engine import set_option
+    if a.subbatch is not None:
+        set_option("subbatch", a.subbatch)
+    if a.stagger_level is not None:
+        set_option("stagger_level", a.stagger_level)
     rank, world, local = D.init_from_env()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
