@@ -120,6 +120,12 @@ int use_sde_corrector(use_handle* h, int corrector, float t, float snr, int B, c
  * the handle is unconditional and may be null when it is conditional only if no_sigma_scale... (not supported: give t). */
 int use_forward(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream);
 
+/* Spectrogram glue either side of the sampler, handle-free (ScoreModel.spec_fwd + pad_spec, model_wrapper.py:92-96,275-278,
+ * util/other.py:128-135; ScoreModel.spec_back + crop, model_wrapper.py:98-103,320).  stft: complex64 [B,F,T] (torch.stft
+ * output), Y / X: complex64 [B,1,F,Tpad].  fwd: Y = |S|^e e^{j arg S} * factor, zero for T <= t < Tpad; back: its inverse. */
+int use_spec_fwd(const void* stft, void* Y, int B, int F, int T, int Tpad, float factor, float exponent, use_stream_t s);
+int use_spec_back(const void* X, void* stft, int B, int F, int T, int Tpad, float factor, float exponent, use_stream_t s);
+
 /* Introspection for tests / profiling */
 /* One eager score evaluation with a HIP-event pair around every launch of the dominant kernel (conv_v4_kernel, the
  * wide-tile implicit-GEMM 3x3 convolution of the large feature maps): summed kernel time, their algorithmic FLOPs and

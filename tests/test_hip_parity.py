@@ -149,6 +149,24 @@ def test_packed_weight_file_round_trip(tmp_path, golden_dir, engines, sd_np):
     e2.close()
 
 
+def test_spectrogram_glue_kernels_match_torch():
+    """use_spec_fwd / use_spec_back = spec_fwd + pad_spec / spec_back of the reference (model_wrapper.py:92-103)."""
+    from universal_speech_enhancement_amd.hip_engine import spec_compress_pad, spec_decompress_crop
+    wav = torch.from_numpy(tnoise.synth_noisy_speech(3, 9000, seed=5))
+    S = so.stft(wav)
+    S[0, 3, 5] = 0                                            # |z| = 0 stays 0
+    ref = so.pad_spec(so.spec_fwd(S).unsqueeze(1))
+    Y = spec_compress_pad(S.cuda(), 0.15, 0.5)
+    assert Y.shape == ref.shape and _relmax(Y, ref) < 1e-6 and float(Y[0, 0, 3, 5].abs()) == 0.0
+    assert float(Y[..., S.shape[2]:].abs().max()) == 0.0
+    back = spec_decompress_crop(Y, S.shape[2], 0.15, 0.5)
+    assert _relmax(back, S) < 1e-5
+    full = spec_decompress_crop(Y, Y.shape[3], 0.15, 0.5)
+    assert _relmax(full, so.spec_back(ref.squeeze(1))) < 1e-5
+    with pytest.raises(UseHipError):
+        spec_compress_pad(S, 0.15, 0.5)                       # CPU tensor
+
+
 def test_odd_widths_at_the_bottom_of_the_unet_fp32(engines, sd_np):
     """T' = 192 = 3 x 64: feature-map widths 192, 96, 48, 24, 12, 6, 3 -- partially filled tiles in every conv kernel
     (conv_v4 at 512x192, conv_v2 at 48 / 24 columns, conv_kernel at 12 / 6 / 3) and odd FIR sizes.  Against the CPU oracle."""

@@ -1107,6 +1107,19 @@ int use_sample(use_handle* h, const void* y, const void* noise, uint64_t seed, v
     return USE_OK;
 }
 
+int use_spec_fwd(const void* stft, void* Y, int B, int F, int T, int Tpad, float factor, float exponent, use_stream_t s) {
+    if (!stft || !Y || B < 1 || F < 1 || T < 1 || Tpad < T) return fail(USE_E_INVALID, "bad arguments");
+    launch_spec_map((const float2*)stft, (float2*)Y, (long)B * F, T, T, Tpad, 1.f, exponent, factor, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+int use_spec_back(const void* X, void* stft, int B, int F, int T, int Tpad, float factor, float exponent, use_stream_t s) {
+    if (!stft || !X || B < 1 || F < 1 || T < 1 || Tpad < T || factor == 0.f || exponent == 0.f) return fail(USE_E_INVALID, "bad arguments");
+    launch_spec_map((const float2*)X, (float2*)stft, (long)B * F, T, Tpad, T, 1.f / factor, 1.f / exponent, 1.f, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+
 int use_sde_prior(use_handle* h, const void* y, const void* noise, uint64_t seed, void* x, int64_t n, use_stream_t s) {
     int rc = ensure_sde_scratch(h); if (rc) return rc;
     hipLaunchKernelGGL(set_rng_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, h->sde_rng, (unsigned long long)seed, 0ull);

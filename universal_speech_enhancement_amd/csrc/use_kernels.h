@@ -74,6 +74,10 @@ void launch_fir_up2(const void* src, int dtype, const float* coef, int act, void
 void launch_fir_down2(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
                       int H, int W, int C, hipStream_t s);
 
+// out[r][t] = z |pre z|^(power-1) pre post for t < Tin (z = in[r][t]), 0 for Tin <= t < Tout  (spectrogram compression glue)
+void launch_spec_map(const float2* in, float2* out, long rows, int Tin, int Tin_stride, int Tout, float pre, float power,
+                     float post, hipStream_t s);
+
 // x4[b,f,t,:] = 2*(x.re, x.im, y.re, y.im) - 1   (fp32), x/y complex64 [B,F,T]
 void launch_pack_input(const float2* x, const float2* y, float* x4, long npix, hipStream_t s);
 

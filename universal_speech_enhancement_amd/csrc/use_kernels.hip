@@ -872,6 +872,35 @@ void launch_fir_up2(const void* src, int dtype, const float* coef, int act, void
 void launch_fir_down2(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
                       int H, int W, int C, hipStream_t s) { fir_launch<false>(src, dtype, coef, act, out_act, out_raw, B, H, W, C, s); }
 
+static int ew_blocks(long n) { long b = (n + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
+// ---------------------------------------------------------------------------------------------------------
+// Spectrogram glue either side of the sampler: magnitude compression + scaling + frame padding, and back
+//   fwd:  Y[b,0,f,t] = |S|^e e^{j arg S} * factor for t < T, 0 for T <= t < Tpad   (model_wrapper.py:92-96, other.py:128-135)
+//   back: S[b,f,t]   = (|X| / factor)^(1/e) e^{j arg X}, t < T                      (model_wrapper.py:98-103, 320)
+// |z|^p e^{j arg z} = z |z|^(p-1) (0 at z = 0, like the reference's abs()**p * exp(1j*angle()))
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spec_map_kernel(const float2* __restrict__ in, float2* __restrict__ out, long rows,
+                                                       int Tin, int Tin_stride, int Tout, float pre, float power, float post) {
+    // rows = B*F; in row stride Tin_stride, Tin valid frames; out row stride Tout (frames >= Tin are zero)
+    const long total = rows * Tout;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / Tout; const int t = (int)(i - r * Tout);
+        float2 o = make_float2(0.f, 0.f);
+        if (t < Tin) {
+            const float2 z = in[r * Tin_stride + t];
+            const float a = hypotf(z.x, z.y) * pre;
+            const float sc = a > 0.f ? powf(a, power - 1.f) * pre * post : 0.f;
+            o = make_float2(z.x * sc, z.y * sc);
+        }
+        out[i] = o;
+    }
+}
+void launch_spec_map(const float2* in, float2* out, long rows, int Tin, int Tin_stride, int Tout, float pre, float power,
+                     float post, hipStream_t s) {
+    hipLaunchKernelGGL(spec_map_kernel, dim3(ew_blocks(rows * Tout)), dim3(256), 0, s, in, out, rows, Tin, Tin_stride, Tout, pre,
+                       power, post);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Input packing
 // ---------------------------------------------------------------------------------------------------------
@@ -884,7 +913,6 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float2* __restric
         x4[i] = make_float4(2.f * a.x - 1.f, 2.f * a.y - 1.f, 2.f * c.x - 1.f, 2.f * c.y - 1.f);
     }
 }
-static int ew_blocks(long n) { long b = (n + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
 void launch_pack_input(const float2* x, const float2* y, float* x4, long npix, hipStream_t s) {
     hipLaunchKernelGGL(pack_input_kernel, dim3(ew_blocks(npix)), dim3(256), 0, s, x, y, (float4*)x4, npix);
 }

@@ -64,7 +64,13 @@ class NCSNPP_Wrapper(nn.Module):
             raise NotImplementedError("the training branch of NCSNPP_Wrapper is outside the scope of the MI355X library")
         y = batch_data["perturbed"]
         T_orig = y.size(1)
-        Y = pad_spec(self.spec_fwd(self.stft(y)).unsqueeze(1)).contiguous()
+        S = self.stft(y)
+        if S.is_cuda:                                         # fused compression + padding / decompression kernels
+            from ..hip_engine import spec_compress_pad, spec_decompress_crop
+            Y = self.net(spec_compress_pad(S, self.spec_factor, self.spec_abs_exponent))
+            batch_data["fake"] = self.istft(spec_decompress_crop(Y, Y.shape[3], self.spec_factor, self.spec_abs_exponent), T_orig)
+            return batch_data
+        Y = pad_spec(self.spec_fwd(S).unsqueeze(1)).contiguous()
         Y = self.net(Y)
         batch_data["fake"] = self.istft(self.spec_back(Y.squeeze(1)), T_orig)
         return batch_data

@@ -36,6 +36,31 @@ def set_option(name: str, value: int) -> None:
     check(_lib.lib().use_set_option(name.encode(), int(value)), "use_set_option")
 
 
+def spec_compress_pad(stft: torch.Tensor, factor: float, exponent: float, multiple: int = 64) -> torch.Tensor:
+    """``pad_spec(spec_fwd(stft).unsqueeze(1))`` in one kernel (``use_spec_fwd``): complex64 CUDA [B,F,T] -> [B,1,F,T']."""
+    if not stft.is_cuda or stft.dtype != torch.complex64 or stft.dim() != 3:
+        raise UseHipError("spec_compress_pad needs a complex64 CUDA tensor [B, F, T]")
+    stft = stft.contiguous()
+    B, F, T = stft.shape
+    Tp = (T + multiple - 1) // multiple * multiple
+    Y = torch.empty((B, 1, F, Tp), dtype=torch.complex64, device=stft.device)
+    check(_lib.lib().use_spec_fwd(stft.data_ptr(), Y.data_ptr(), B, F, T, Tp, float(factor), float(exponent), _stream_ptr(stft.device)),
+          "use_spec_fwd")
+    return Y
+
+
+def spec_decompress_crop(X: torch.Tensor, T: int, factor: float, exponent: float) -> torch.Tensor:
+    """``spec_back(X.squeeze(1))[..., :T]`` in one kernel (``use_spec_back``): complex64 CUDA [B,1,F,T'] -> [B,F,T]."""
+    if not X.is_cuda or X.dtype != torch.complex64 or X.dim() != 4 or X.shape[1] != 1:
+        raise UseHipError("spec_decompress_crop needs a complex64 CUDA tensor [B, 1, F, T']")
+    X = X.contiguous()
+    B, _, F, Tp = X.shape
+    S = torch.empty((B, F, T), dtype=torch.complex64, device=X.device)
+    check(_lib.lib().use_spec_back(X.data_ptr(), S.data_ptr(), B, F, int(T), Tp, float(factor), float(exponent), _stream_ptr(X.device)),
+          "use_spec_back")
+    return S
+
+
 class HipScoreEngine:
     """One handle per (process, device).  Not re-entrant."""
 

@@ -118,7 +118,20 @@ class ScoreModel(nn.Module):
         raise NotImplementedError("the probability-flow ODE sampler (scipy RK45 host solver) is not on the predict path")
 
     def _spectrogram(self, y):
-        return pad_spec(self.spec_fwd(self.stft(y)).unsqueeze(1))
+        """STFT -> compression -> pad to a multiple of 64 frames (reference :275-278); one fused kernel on the device."""
+        S = self.stft(y)
+        if S.is_cuda:
+            from ..hip_engine import spec_compress_pad
+            return spec_compress_pad(S, self.spec_factor, self.spec_abs_exponent)
+        return pad_spec(self.spec_fwd(S).unsqueeze(1))
+
+    def _waveform(self, X, T_orig):
+        """decompression -> iSTFT (reference :320).  All T' frames go into the iSTFT, as in the reference: the frames of
+        the padding region overlap the last n_fft/2 samples of the signal."""
+        if X.is_cuda:
+            from ..hip_engine import spec_decompress_crop
+            return self.istft(spec_decompress_crop(X, X.shape[3], self.spec_factor, self.spec_abs_exponent), T_orig)
+        return self.istft(self.spec_back(X.squeeze(1)), T_orig)
 
     def sample(self, batch, sampler_type="pc", N=50, corrector_steps=1, snr=0.5, noise=None, seed=0):
         """Reference :262-329: adds ``batch['enhanced']`` (float32 [B, L]) for condition / sde_input 'noisy'."""
@@ -134,7 +147,7 @@ class ScoreModel(nn.Module):
         sampler = self.get_pc_sampler(self.predictor, self.corrector, Y, N=N, corrector_steps=corrector_steps, snr=snr,
                                       intermediate=False, conditioning=[Y], noise=noise, seed=seed)
         sample, nfe = sampler()
-        batch["enhanced"] = self.istft(self.spec_back(sample.squeeze(1)), T_orig)
+        batch["enhanced"] = self._waveform(sample, T_orig)
         return batch
 
     @torch.no_grad()
@@ -156,7 +169,7 @@ class ScoreModel(nn.Module):
                                           intermediate=False, conditioning=[Y], noise=noise, seed=seed)()
         if return_stft:
             return sample.squeeze(), Y.squeeze(), T_orig, norm_factor
-        x_hat = (self.istft(self.spec_back(sample.squeeze(1)), T_orig) * norm_factor).squeeze().cpu()
+        x_hat = (self._waveform(sample, T_orig) * norm_factor).squeeze().cpu()
         if timeit:
             return x_hat, nfe, (time.time() - start) / (len(x_hat) / sr)
         return x_hat
