@@ -16,18 +16,10 @@ import torch.nn as nn
 from . import sampling
 from .backbones import BackboneRegistry
 from .sdes import SDERegistry
-from .util.other import pad_spec
+from .util.spectral import SpectralGlue, get_window  # noqa: F401  (get_window: part of the reference module's surface)
 
 
-def get_window(window_type, window_length):
-    if window_type == "sqrthann":
-        return torch.sqrt(torch.hann_window(window_length, periodic=True))
-    if window_type == "hann":
-        return torch.hann_window(window_length, periodic=True)
-    raise NotImplementedError(f"Window type {window_type} not implemented!")
-
-
-class ScoreModel(nn.Module):
+class ScoreModel(SpectralGlue, nn.Module):
     supports_fused_sampler = True
 
     def __init__(self, backbone: str = "ncsnpp", sde: str = "ouve", t_eps: float = 3e-2, mode="regen-joint-training",
@@ -40,39 +32,11 @@ class ScoreModel(nn.Module):
                           if backbone != "none" else None)
         self.sde = SDERegistry.get_by_name(sde)()
         self.t_eps, self.condition, self.mode, self.loss_type = t_eps, condition, mode, loss_type
-        self.n_fft, self.hop_length, self.num_frames = n_fft, hop_length, num_frames
-        self.window = get_window(window, n_fft)
-        self.windows = {}
-        self.spec_factor, self.spec_abs_exponent = spec_factor, spec_abs_exponent
-        self.target_len = (num_frames - 1) * hop_length
+        self._init_spectral(n_fft, hop_length, num_frames, window, spec_factor, spec_abs_exponent)
         self.sde_input, self.predictor, self.corrector = sde_input, predictor, corrector
         self.precision, self.use_graph = precision, use_graph
 
-    # ---- STFT glue (reference :92-122) -------------------------------------------------------------------
-    def spec_fwd(self, spec):
-        if self.spec_abs_exponent != 1:
-            spec = spec.abs() ** self.spec_abs_exponent * torch.exp(1j * spec.angle())
-        return spec * self.spec_factor
-
-    def spec_back(self, spec):
-        spec = spec / self.spec_factor
-        if self.spec_abs_exponent != 1:
-            spec = spec.abs() ** (1 / self.spec_abs_exponent) * torch.exp(1j * spec.angle())
-        return spec
-
-    def _get_window(self, x):
-        w = self.windows.get(x.device)
-        if w is None:
-            w = self.windows[x.device] = self.window.to(x.device)
-        return w
-
-    def stft(self, sig):
-        return torch.stft(sig, n_fft=self.n_fft, hop_length=self.hop_length, window=self._get_window(sig), center=True,
-                          return_complex=True)
-
-    def istft(self, spec, length=None):
-        return torch.istft(spec, n_fft=self.n_fft, hop_length=self.hop_length, window=self._get_window(spec), center=True,
-                           length=length)
+    # STFT glue (reference :92-122): SpectralGlue
 
     # ---- score function (reference :135-145) -------------------------------------------------------------
     def forward_score(self, x, t, score_conditioning, sde_input):
@@ -116,22 +80,6 @@ class ScoreModel(nn.Module):
 
     def get_ode_sampler(self, *args, **kwargs):
         raise NotImplementedError("the probability-flow ODE sampler (scipy RK45 host solver) is not on the predict path")
-
-    def _spectrogram(self, y):
-        """STFT -> compression -> pad to a multiple of 64 frames (reference :275-278); one fused kernel on the device."""
-        S = self.stft(y)
-        if S.is_cuda:
-            from ..hip_engine import spec_compress_pad
-            return spec_compress_pad(S, self.spec_factor, self.spec_abs_exponent)
-        return pad_spec(self.spec_fwd(S).unsqueeze(1))
-
-    def _waveform(self, X, T_orig):
-        """decompression -> iSTFT (reference :320).  All T' frames go into the iSTFT, as in the reference: the frames of
-        the padding region overlap the last n_fft/2 samples of the signal."""
-        if X.is_cuda:
-            from ..hip_engine import spec_decompress_crop
-            return self.istft(spec_decompress_crop(X, X.shape[3], self.spec_factor, self.spec_abs_exponent), T_orig)
-        return self.istft(self.spec_back(X.squeeze(1)), T_orig)
 
     def sample(self, batch, sampler_type="pc", N=50, corrector_steps=1, snr=0.5, noise=None, seed=0):
         """Reference :262-329: adds ``batch['enhanced']`` (float32 [B, L]) for condition / sde_input 'noisy'."""
