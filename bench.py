@@ -48,20 +48,20 @@ def usable_cores():
 
 
 def cpu_baseline(sd_np):
-    """CPU oracle on a bounded sample: one 64-frame score evaluation per thread-count candidate (the best is kept: torch's
-    CPU conv does not scale to hundreds of threads on this shape), then a PC sampler with Langevin x1 on 2 utterances of
-    128 frames at the best thread count, N chosen so the sample takes roughly 10-30 s."""
+    """CPU oracle timed per SURVEY.md section 8d: BASELINE configs[0] / cfg1 exactly -- ONE 2 s utterance (L=48000, T=301 frames,
+    T'=320), N=5 reverse steps, reverse_diffusion + Langevin x1, snr 0.5 => 10 score evaluations, fp32 -- on this box's host
+    cores.  The thread count is the best of a short probe (one 64-frame score evaluation per candidate: torch's CPU conv does
+    not scale to hundreds of threads on this shape).  Cost per evaluation is constant in t, so the rate is scaled linearly
+    in NFE to the metric's 60-NFE sampler."""
     from oracle import ncsnpp_oracle as no
     from oracle import sde_oracle as so
     from universal_speech_enhancement_amd.testing import noise as tn
     avail = usable_cores()
     sd = no.to_torch(sd_np)
-    L = 63 * 160
-    wav = torch.from_numpy(tn.synth_noisy_speech(1, L, seed=4242))
     x = torch.from_numpy(tn.complex_normal(1, "cpu_x", (1, 2, 512, 64)))
     best, best_dt = None, 1e30
     with torch.no_grad():
-        for th in sorted({min(avail, c) for c in (8, 32, avail)}):
+        for th in sorted({min(avail, c) for c in (8, 16, 32, avail)}):
             torch.set_num_threads(th)
             t0 = time.time()
             no.ncsnpp_forward(sd, x, torch.tensor([0.5]))
@@ -71,12 +71,9 @@ def cpu_baseline(sd_np):
             if d > 20.0:
                 break
         torch.set_num_threads(best)
-        est_rate = 64.0 / best_dt                                   # frame*NFE/s from the probe
-        n_utt, fr = 2, 128
-        N = int(max(1, min(15, round(est_rate * 15.0 / (n_utt * fr * 2)))))   # aim at ~15 s of CPU work
-        L = (fr - 1) * 160
-        wav = torch.from_numpy(tn.synth_noisy_speech(n_utt, L, seed=4242))
-        draws = [torch.from_numpy(d) for d in tn.sampler_noise(1, 1 + 2 * N, (n_utt, 1, 512, fr))]
+        n_utt, L, N = 1, 48000, 5
+        wav = torch.from_numpy(tn.synth_noisy_speech(n_utt, L, seed=1234))
+        draws = [torch.from_numpy(d) for d in tn.sampler_noise(4321, 1 + 2 * N, (n_utt, 1, 512, 320))]
         t0 = time.time()
         _, _, Y, nfe = so.score_model_sample(lambda xx, t: no.ncsnpp_forward(sd, xx, t), wav, N=N, corrector="langevin",
                                              corrector_steps=1, snr=0.5, noise=so.NoiseSource(replay=draws))
@@ -84,8 +81,10 @@ def cpu_baseline(sd_np):
     frames = n_utt * (1 + L // 160)
     frame_nfe_per_s = frames * nfe / dt
     return {"value": round(frame_nfe_per_s / 60.0, 4), "unit": "spectrogram-frames/s", "cores": best, "kind": "port",
-            "sample": f"CPU oracle (torch fp32, {best} of {avail} usable cores): {n_utt} utterances x {fr} frames, {N}-step PC "
-                      f"sampler = {nfe} NFE in {dt:.1f} s ({frame_nfe_per_s:.1f} frame*NFE/s), scaled linearly to 60 NFE"}
+            "sample": f"CPU oracle (torch fp32, {best} of {avail} usable cores) on BASELINE configs[0] exactly: 1 utterance x 2 s "
+                      f"({frames} frames, T'=320), 5-step PC sampler (reverse_diffusion + langevin x1) = {nfe} NFE in {dt:.1f} s "
+                      f"({frame_nfe_per_s:.1f} frame*NFE/s; {frames / dt:.2f} frames/s at this 10-NFE sampler), scaled linearly in "
+                      f"NFE to the metric's 60-NFE sampler"}
 
 
 def main():

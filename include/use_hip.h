@@ -62,7 +62,7 @@ typedef struct use_sampler_config {
     int use_graph;         /* 1: capture the whole loop in a hipGraph and replay it                    */
 } use_sampler_config;
 
-/* Process-wide tuning knobs (no reference counterpart).  "subbatch" (default 1): batches of >= 4 items are evaluated as
+/* Process-wide tuning knobs (no reference counterpart).  "subbatch" (default 2): batches of >= 4 items are evaluated as
  * two halves on two streams, staggered so that the small-map kernels of one half run beside the large convolutions of
  * the other; items never interact inside the network, so results are identical to subbatch = 0 (read at use_plan).  "conv_v4_min_blocks": smallest per-image grid (workgroups) the
  * wide-tile convolution kernel is selected for, default 128; results do not depend on it beyond rounding order. */

@@ -14,7 +14,8 @@ Fixtures
   resblock_*.npz    ResnetBlockBigGANpp plain / widen / down / up / cat-input        (G1)
   attn.npz          AttnBlockpp [2,32,8,5]                                          (G1)
   forward_large.npz NCSNppLarge.forward [2,2,512,64], t in {1.0,0.5} and {0.03,0.2}  (G2)
-  sampler_*.npz     get_pc_sampler with an analytic score_fn, N=7                    (G3)
+  sampler_*.npz     get_pc_sampler with an analytic score_fn, N=7: reverse_diffusion x {none, langevin, ald},
+                    euler_maruyama x {none, langevin}                                (G3)
   sample_e2e.npz    ScoreModel.sample, 0.4 s utterance, N=3, langevin x1             (G4)
   sample_cfg1.npz   BASELINE cfg1: 2 s utterance, N=5, reverse_diffusion+langevin    (G5, ~70 s)
   refine.npz        LSGAN refine generator: NCSNpp(discriminative=True).forward [2,1,512,64] and
@@ -159,6 +160,32 @@ def gen_samplers():
                  noise_seed=33, n_draws=ndraw, N=7, corrector_steps=2, snr=0.5, eps=0.03)
 
 
+def gen_samplers_em():
+    """EulerMaruyamaPredictor (sampling/predictors.py:40-53 over RSDE.sde / rsde_parts, sdes.py:119-157).  On the reference's
+    own predict path this predictor raises (rsde_parts calls score_model(x, t, conditioning) without sde_input, sdes.py:128);
+    the sampler accepts any callable, so a score_fn with optional trailing arguments reaches the formula."""
+    Y = torch.from_numpy(tnoise.complex_normal(21, "samp_y", (3, 1, 16, 8)))
+    A = torch.from_numpy(tnoise.complex_normal(21, "samp_a", (1, 1, 16, 8)))
+
+    def score_fn(x, t, score_conditioning=None, sde_input=None):
+        c = score_conditioning[0]                            # == Y; sde_input is not passed on this route
+        return -(x - 0.8 * c) / (0.1 + t[:, None, None, None] ** 2) + 0.05 * A * torch.tanh(x.abs())
+
+    for corr in ("none", "langevin"):
+        sde = OUVESDE(); sde.N = 7
+        ndraw = 1 + 7 * (1 + (0 if corr == "none" else 2))
+        draws = tnoise.sampler_noise(34, ndraw, tuple(Y.shape))
+        orig = torch.randn_like
+        torch.randn_like = _Replay(list(draws))
+        try:
+            x, nfe = ref_sampling.get_pc_sampler("euler_maruyama", corr, sde=sde, score_fn=score_fn, y=Y, eps=0.03,
+                                                 snr=0.5, corrector_steps=2, conditioning=[Y])()
+        finally:
+            torch.randn_like = orig
+        np.savez(os.path.join(OUT, f"sampler_em_{corr}.npz"), Y=Y.numpy(), A=A.numpy(), x=x.numpy(), nfe=nfe,
+                 noise_seed=34, n_draws=ndraw, N=7, corrector_steps=2, snr=0.5, eps=0.03)
+
+
 def _sample_case(m, crc, fname, n_utts, length, N, corrector_steps, seed):
     wav = torch.from_numpy(tnoise.synth_noisy_speech(n_utts, length, seed=seed))
     T = 1 + length // 160
@@ -210,7 +237,8 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    small = {"fir": gen_fir, "resblocks": gen_resblocks, "attn": gen_attn, "samplers": gen_samplers, "refine": gen_refine}
+    small = {"fir": gen_fir, "resblocks": gen_resblocks, "attn": gen_attn, "samplers": gen_samplers, "samplers_em": gen_samplers_em,
+             "refine": gen_refine}
     big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1}
     todo = [a.only] if a.only else list(small) + list(big)
     model = build_reference_large() if any(n in big for n in todo) else None

@@ -495,7 +495,6 @@ bool conv_v2_eligible(const ConvArgs& a) {
 }
 
 void launch_conv_v2(const ConvArgs& a0, hipStream_t s) {
-    static const bool use_v3 = getenv("USE_HIP_V3") != nullptr && atoi(getenv("USE_HIP_V3")) != 0;
     ConvArgs a = a0;
     static const int dbg = getenv("USE_HIP_DBG") ? atoi(getenv("USE_HIP_DBG")) : 0;
     a.dbg = dbg;
@@ -507,8 +506,7 @@ void launch_conv_v2(const ConvArgs& a0, hipStream_t s) {
         if (!printed && a.H == 512 && a.C0 + a.C1 == want_c) {
             (void)hipMemsetAsync(trace_buf, 0, 512 * 8, s);
             a.trace = trace_buf;
-            if (use_v3) launch_conv_v3(a, s);
-            else if (a.in_dtype == DT_BF16) { a.act ? v2_launch_t<__bf16, __bf16, 64, true>(a, s) : v2_launch_t<__bf16, __bf16, 64, false>(a, s); }
+            if (a.in_dtype == DT_BF16) { a.act ? v2_launch_t<__bf16, __bf16, 64, true>(a, s) : v2_launch_t<__bf16, __bf16, 64, false>(a, s); }
             (void)hipStreamSynchronize(s);
             unsigned long long hbuf[512];
             (void)hipMemcpy(hbuf, trace_buf, sizeof hbuf, hipMemcpyDeviceToHost);
@@ -523,7 +521,6 @@ void launch_conv_v2(const ConvArgs& a0, hipStream_t s) {
             a.trace = nullptr;
         }
     }
-    if (use_v3) { launch_conv_v3(a, s); return; }
     if (a.in_dtype == DT_BF16) { a.act ? v2_launch_t<__bf16, __bf16, 64, true>(a, s) : v2_launch_t<__bf16, __bf16, 64, false>(a, s); }
     else                       { a.act ? v2_launch_t<float, float, 32, true>(a, s) : v2_launch_t<float, float, 32, false>(a, s); }
 }

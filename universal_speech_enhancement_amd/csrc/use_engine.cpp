@@ -783,6 +783,8 @@ int use_alloc_weight_blob(use_handle* h) {
     HIPCHK(hipSetDevice(h->device));
     if (!h->blob) HIPCHK(hipMalloc((void**)&h->blob, h->blob_bytes));
     h->weights_ready = true;   // contents to be filled by the caller's broadcast
+    h->sampler_set = false;    // the time-embedding table was built from the previous contents
+    drop_graphs(h);
     return USE_OK;
 }
 

@@ -50,7 +50,6 @@ void launch_conv(const ConvArgs& a, hipStream_t s);
 // software-pipelined variant for large maps (use_conv_v2.hip); launch_conv dispatches to it when eligible
 bool conv_v2_eligible(const ConvArgs& a);
 void launch_conv_v2(const ConvArgs& a, hipStream_t s);
-void launch_conv_v3(const ConvArgs& a, hipStream_t s);   // wave-specialised variant (use_conv_v3.hip), same tiles as v2
 // wide-tile variant (use_conv_v4.hip): 16x32-pixel tiles, K chunks of conv_v4_chunk() channels, slab-major weights
 inline int conv_v4_chunk(int dtype) { return dtype == DT_BF16 ? 32 : 16; }
 inline int conv_v4_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 31) / 32); }

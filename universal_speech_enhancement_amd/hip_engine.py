@@ -107,6 +107,7 @@ class HipScoreEngine:
         """Start from a packed weight file instead of a state dict (``use_load_weight_blob``)."""
         check(self.L.use_load_weight_blob(self.h, os.fsencode(path)), "use_load_weight_blob")
         self.weights_ready = True
+        self.sampler_key = None                               # the library dropped its time-embedding table and graphs
 
     def expected_weights(self) -> Dict[str, tuple]:
         out = {}

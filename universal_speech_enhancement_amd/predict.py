@@ -88,8 +88,9 @@ def predict(cfg: dict):
     data = instantiate(cfg["data"], rank=rank, world_size=world)
     model = instantiate(cfg["model"])
     if cfg.get("ckpt_path") and str(cfg["ckpt_path"]).endswith(".usehip"):   # packed weight file (pack_checkpoint)
+        owner = model.G if hasattr(model, "G") else model.Score            # the module that carries n_fft
         net = model.G.net if hasattr(model, "G") else model.Score.score_net
-        net.load_weight_file(cfg["ckpt_path"], device=torch.device("cuda", local))
+        net.load_weight_file(cfg["ckpt_path"], n_freq=int(owner.n_fft) // 2 + 1, device=torch.device("cuda", local))
     elif cfg.get("ckpt_path"):
         model.load_lightning_checkpoint(cfg["ckpt_path"])
     elif cfg.get("random_init_seed") is not None:

@@ -90,38 +90,54 @@ class NCSNpp(nn.Module):
                 node = getattr(node, p)
             node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=False))
         self._engine = None
+        self._engine_sde = self._DEFAULT_SDE
         self._engine_dirty = True
-        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_engine_dirty", True))
+        self._weight_file = None                             # set by load_weight_file: the engine's weights come from it
+
+        def _on_load(module, incompatible):                  # a state dict replaces whatever a weight file provided
+            module._engine_dirty, module._weight_file = True, None
+        self.register_load_state_dict_post_hook(_on_load)
 
     # -- engine management --------------------------------------------------------------------------------
-    def engine(self, n_freq: int, device=None):
+    _DEFAULT_SDE = (1.5, 0.05, 0.5)
+
+    def _new_engine(self, n_freq, device, sde_constants):
         from ...hip_engine import HipScoreEngine
-        if self._engine is None or self._engine.n_freq != n_freq:
-            self._engine = HipScoreEngine(nf=self.nf, ch_mult=self.ch_mult, num_res_blocks=self.num_res_blocks,
-                                          n_freq=n_freq, precision=self.precision,
-                                          device=None if device is None else torch.device(device).index,
-                                          input_channels=self.input_channels, conditional=self.conditional,
-                                          scale_by_sigma=self.scale_by_sigma)
+        th, smin, smax = sde_constants
+        return HipScoreEngine(nf=self.nf, ch_mult=self.ch_mult, num_res_blocks=self.num_res_blocks, n_freq=n_freq,
+                              precision=self.precision, device=None if device is None else torch.device(device).index,
+                              theta=th, sigma_min=smin, sigma_max=smax, input_channels=self.input_channels,
+                              conditional=self.conditional, scale_by_sigma=self.scale_by_sigma)
+
+    def engine(self, n_freq: int, device=None, sde_constants=None):
+        """The ``use_handle`` for ``n_freq`` bins (and the OUVE constants of the fused sampler); rebuilt when either
+        changes.  Weights come from the packed file when ``load_weight_file`` was used, else from the module's
+        parameters."""
+        want = tuple(float(v) for v in (sde_constants or self._engine_sde))
+        if self._engine is None or self._engine.n_freq != n_freq or self._engine_sde != want:
+            self._engine = self._new_engine(n_freq, device, want)
+            self._engine_sde = want
             self._engine_dirty = True
         if self._engine_dirty:
-            self._engine.load_state_dict(self.state_dict())
+            if self._weight_file is not None:
+                self._engine.load_weight_blob(self._weight_file)
+            else:
+                self._engine.load_state_dict(self.state_dict())
             self._engine_dirty = False
         return self._engine
 
     def load_weight_file(self, path: str, n_freq: int = 512, device=None):
         """Start from a packed weight file (``pack_checkpoint``; ``use_load_weight_blob``) instead of a state dict: the
-        module's own parameters are left untouched and no longer consulted."""
-        from ...hip_engine import HipScoreEngine
-        self._engine = HipScoreEngine(nf=self.nf, ch_mult=self.ch_mult, num_res_blocks=self.num_res_blocks, n_freq=n_freq,
-                                      precision=self.precision, device=None if device is None else torch.device(device).index,
-                                      input_channels=self.input_channels, conditional=self.conditional,
-                                      scale_by_sigma=self.scale_by_sigma)
-        self._engine.load_weight_blob(path)
-        self._engine_dirty = False
+        module's own parameters are left untouched and no longer consulted -- until ``load_state_dict`` /
+        ``refresh_weights`` hands the module's parameters back to the engine."""
+        self._weight_file = str(path)
+        self._engine = None
+        self._engine_dirty = True
+        self.engine(n_freq, device)
 
     def refresh_weights(self):
         """Call after modifying parameters in place (``load_state_dict`` is tracked automatically)."""
-        self._engine_dirty = True
+        self._engine_dirty, self._weight_file = True, None
 
     def forward(self, x: torch.Tensor, time_cond: torch.Tensor = None) -> torch.Tensor:
         nin = self.input_channels // 2

@@ -50,9 +50,11 @@ class ScoreModel(SpectralGlue, nn.Module):
         raise NotImplementedError("training is outside the scope of the MI355X sampling library (inference only)")
 
     # ---- samplers (reference :210-260) -------------------------------------------------------------------
-    def fused_sample(self, y, N, predictor, corrector, corrector_steps, snr, t_eps, noise=None, seed=0, use_graph=True):
-        """Whole PC loop inside libuse_hip.so (``use_sample``)."""
-        eng = self.score_net.engine(y.shape[2], y.device)
+    def fused_sample(self, y, N, predictor, corrector, corrector_steps, snr, t_eps, noise=None, seed=0, use_graph=True,
+                     sde=None):
+        """Whole PC loop inside libuse_hip.so (``use_sample``), with the OUVE constants of ``sde`` (default: ``self.sde``)."""
+        sde = self.sde if sde is None else sde
+        eng = self.score_net.engine(y.shape[2], y.device, sde_constants=(sde.theta, sde.sigma_min, sde.sigma_max))
         eng.plan(y.shape[0], y.shape[3])
         eng.set_sampler(N, predictor, corrector, corrector_steps, snr, t_eps, use_graph=use_graph)
         return eng.sample(y, noise=noise, seed=seed)

@@ -50,7 +50,11 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=Tru
     builtin = (isinstance(predictor, (_HipPredictor, NonePredictor)) and isinstance(corrector, (_HipCorrector, NoneCorrector))
                and type(predictor) in (PredictorRegistry.get_by_name(n) for n in ("reverse_diffusion", "euler_maruyama", "none"))
                and type(corrector) in (CorrectorRegistry.get_by_name(n) for n in ("langevin", "ald", "none")))
-    fused = (builtin and not probability_flow and denoise and getattr(score_fn, "supports_fused_sampler", False)
+    from ..sdes import OUVESDE
+    # the fused loop implements the OUVE dynamics of exactly this class (subclasses / other registered SDEs take the seam path);
+    # its constants travel with the call so that the engine is rebuilt when they differ from the defaults
+    fused = (builtin and type(sde) is OUVESDE and not probability_flow and denoise
+             and getattr(score_fn, "supports_fused_sampler", False)
              and conditioning is not None and len(conditioning) == 1 and conditioning[0] is y)
 
     if fused:
@@ -58,7 +62,7 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=Tru
             with torch.no_grad():
                 x = score_fn.fused_sample(y, N=sde.N, predictor=predictor_name, corrector=corrector_name,
                                           corrector_steps=corrector_steps, snr=snr, t_eps=eps, noise=noise, seed=seed,
-                                          use_graph=use_graph)
+                                          use_graph=use_graph, sde=sde)
             return x, sde.N * (corrector.n_steps + 1)
         return pc_sampler
 
