@@ -33,7 +33,7 @@ typedef struct use_handle use_handle;
 typedef void* use_stream_t; /* hipStream_t */
 
 enum { USE_OK = 0, USE_E_INVALID = -1, USE_E_HIP = -2, USE_E_STATE = -3, USE_E_NOMEM = -4 };
-enum { USE_PREC_FP32 = 0, USE_PREC_BF16 = 1 };
+enum { USE_PREC_FP32 = 0, USE_PREC_BF16 = 1, USE_PREC_FP16 = 2 };   /* storage of activations / conv weights; accumulation is always fp32 */
 enum { USE_PRED_REVERSE_DIFFUSION = 0, USE_PRED_EULER_MARUYAMA = 1, USE_PRED_NONE = 2 };
 enum { USE_CORR_NONE = 0, USE_CORR_LANGEVIN = 1, USE_CORR_ALD = 2 };
 
@@ -133,6 +133,19 @@ int use_spec_back(const void* X, void* stft, int B, int F, int T, int Tpad, floa
  * Synchronises the stream. */
 int use_profile_score(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream,
                       double* conv_ms, double* conv_flops, double* conv_bytes, int* conv_launches, double* total_ms);
+/* Single-convolution harness for kernel bring-up and same-box A/B timing (no reference counterpart): builds one fused
+ * implicit-GEMM 3x3 convolution (optional second channel-concat source C1, GroupNorm affine + SiLU on the input, bias +
+ * time-embedding bias, fused 1x1 shortcut over XC0+XC1 channels, residual, GroupNorm partial sums) on deterministic
+ * pseudo-random device data, runs it `iters` times through the chosen kernel (variant 0: the library's dispatcher, 2 / 4 / 5:
+ * conv_v2 / conv_v4 / conv_v5) and returns the average launch time, the algorithmic FLOPs, the output as float32
+ * [B][H][W][Cout] (host, may be null) and the per-(item, channel) (sum, sum of squares) totals [B][Cout][2] (host, may be null). */
+typedef struct use_conv_case {
+    int B, H, W, C0, C1, Cout, XC0, XC1;
+    int act, gn, temb, res, stats;   /* flags */
+    int dtype;                       /* 0 fp32, 1 bf16, 2 fp16 (storage) */
+    int variant, iters;
+} use_conv_case;
+int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, double* ms_avg, double* flops);
 /* timesteps of the sampler, torch.linspace(1, t_eps, N) float32 semantics (sampling/__init__.py:63); host only */
 int use_timesteps(int N, float t_eps, float* out);
 int use_debug_tensor(use_handle* h, const char* name, void** dev_ptr, int* dims4, int* dtype);

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libuse_hip.so")
 
-PREC = {"fp32": 0, "bf16": 1}
+PREC = {"fp32": 0, "bf16": 1, "fp16": 2}
 PREDICTORS = {"reverse_diffusion": 0, "euler_maruyama": 1, "none": 2}
 CORRECTORS = {"none": 0, "langevin": 1, "ald": 2}
 
@@ -27,6 +27,11 @@ class UseConfig(C.Structure):
 class UseSamplerConfig(C.Structure):
     _fields_ = [("N", C.c_int), ("predictor", C.c_int), ("corrector", C.c_int), ("corrector_steps", C.c_int),
                 ("snr", C.c_float), ("t_eps", C.c_float), ("use_graph", C.c_int)]
+
+
+class UseConvCase(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("B", "H", "W", "C0", "C1", "Cout", "XC0", "XC1", "act", "gn", "temb", "res", "stats",
+                                       "dtype", "variant", "iters")]
 
 
 class UseHipError(RuntimeError):
@@ -68,6 +73,7 @@ SYMBOLS = {
     "use_flops_per_score": (C.c_double, [_vp]),
     "use_profile_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double)]),
     "use_timesteps": (_i, [_i, _f, C.POINTER(_f)]),
+    "use_conv_bench": (_i, [C.POINTER(UseConvCase), _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 

@@ -374,6 +374,16 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
     const int ch = lane % CPR;
     const int co0 = n0 + wn * NW + ch * CH;
     const bool cok = co0 < p.Cout;
+    // Combine ('sum') weights of this lane's channels: loop-invariant, fetched once (they were re-read per pixel piece)
+    constexpr bool HOIST_W4 = sizeof(TOUT) == 2;             // fp32 parity kernels: no registers to spare, in-loop loads
+    float4 w4r[CH]; float b4r[CH];
+    if (HOIST_W4 && p.pyr && cok) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { w4r[c] = *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4); b4r[c] = p.b4[co0 + c]; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { w4r[c] = make_float4(0.f, 0.f, 0.f, 0.f); b4r[c] = 0.f; }
+    }
     float st_s[CH], st_q[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) { st_s[c] = 0.f; st_q[c] = 0.f; }
@@ -428,8 +438,8 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
                     const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
-                        const float4 wq = *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4);
-                        v[c] += p.b4[co0 + c] + wq.x * pq.x + wq.y * pq.y + wq.z * pq.z + wq.w * pq.w;
+                        const float4 wq = HOIST_W4 ? w4r[c] : *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4);
+                        v[c] += (HOIST_W4 ? b4r[c] : p.b4[co0 + c]) + wq.x * pq.x + wq.y * pq.y + wq.z * pq.z + wq.w * pq.w;
                     }
                 }
                 const uint4 packed = Vec16<TOUT>::pack(v);
@@ -489,7 +499,7 @@ static void v2_launch_t(const ConvArgs& a, hipStream_t s) {
 
 bool conv_v2_eligible(const ConvArgs& a) {
     const int Ctot = a.C0 + a.C1, XC = a.XC0 + a.XC1;
-    const int ck = a.in_dtype == DT_BF16 ? 64 : 32;
+    const int ck = a.in_dtype == DT_F32 ? 32 : 64;
     return a.ntaps == 9 && a.Cout > 32 && a.in_dtype == a.out_dtype && Ctot % ck == 0 && XC % ck == 0 && a.H >= V2_T &&
            a.W >= V2_T;
 }
@@ -521,8 +531,9 @@ void launch_conv_v2(const ConvArgs& a0, hipStream_t s) {
             a.trace = nullptr;
         }
     }
-    if (a.in_dtype == DT_BF16) { a.act ? v2_launch_t<__bf16, __bf16, 64, true>(a, s) : v2_launch_t<__bf16, __bf16, 64, false>(a, s); }
-    else                       { a.act ? v2_launch_t<float, float, 32, true>(a, s) : v2_launch_t<float, float, 32, false>(a, s); }
+    if (a.in_dtype == DT_BF16)     { a.act ? v2_launch_t<__bf16, __bf16, 64, true>(a, s) : v2_launch_t<__bf16, __bf16, 64, false>(a, s); }
+    else if (a.in_dtype == DT_F16) { a.act ? v2_launch_t<_Float16, _Float16, 64, true>(a, s) : v2_launch_t<_Float16, _Float16, 64, false>(a, s); }
+    else                           { a.act ? v2_launch_t<float, float, 32, true>(a, s) : v2_launch_t<float, float, 32, false>(a, s); }
 }
 
 }  // namespace use

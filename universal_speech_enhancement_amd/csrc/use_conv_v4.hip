@@ -26,25 +26,6 @@ constexpr int V4_TW = 32, V4_TH = 16;             // tile: 16 rows x 32 columns
 constexpr int V4_HW = V4_TW + 2, V4_HH = V4_TH + 2;
 constexpr int V4_BN = 128;
 
-template <typename TIN, bool ACT>
-DEVI uint4 v4_transform(const uint4 raw, const unsigned mask, const float (&ca)[16 / sizeof(TIN)],
-                        const float (&cb)[16 / sizeof(TIN)]) {
-    constexpr int VEC = 16 / sizeof(TIN);
-    float v[VEC];
-    Vec16<TIN>::load(reinterpret_cast<const TIN*>(&raw), v);
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        v[k] = fmaf(v[k], ca[k], cb[k]);
-        if (ACT) {
-            if (sizeof(TIN) == 4) v[k] = v[k] / (1.0f + expf(-v[k]));        // fp32 parity mode: accurate
-            else v[k] = v[k] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[k] * -1.44269504088896341f));
-        }
-    }
-    uint4 o = Vec16<TIN>::pack(v);
-    o.x &= mask; o.y &= mask; o.z &= mask; o.w &= mask;
-    return o;
-}
-
 template <typename TIN, typename TOUT, int CK, bool ACT>
 __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     typedef Mfma<TIN> MF;
@@ -171,7 +152,8 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
 
     // ---- weights: slab-major copy [tap][chunk][cout_pad][CK]; one 16-byte piece per thread per slab ----------------------
     const unsigned wvoff = (unsigned)tid * 16u;
-    const int wdst = 2 * HALO_BYTES + (tid / PARTS) * ROWB + part * 16;
+    // the slab rows of the blob are piece-swizzled (use_kernels.h, ConvArgs::wb): undo it while writing the padded LDS rows
+    const int wdst = 2 * HALO_BYTES + (tid / PARTS) * ROWB + (part ^ (((tid / PARTS) >> 2) & 3)) * 16;
     const unsigned slab_b = (unsigned)(p.cout_pad * CK) * (unsigned)sizeof(TIN);     // bytes per (tap, chunk) slab
     const unsigned n0_b = (unsigned)(n0 * CK) * (unsigned)sizeof(TIN);
     // weights of iteration (chunk CC, tap TT) -> R ; TT may run past 8 (wraps into the next chunk)
@@ -195,7 +177,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         V4_STORE_W(0, w0);
 #pragma unroll
         for (int j = 0; j < PIECE_ITERS; ++j)
-            *reinterpret_cast<uint4*>(smem + (pdst[j] >= 0 ? pdst[j] : dummy_off)) = v4_transform<TIN, ACT>(raw[j], pmask[j], ca, cb);
+            *reinterpret_cast<uint4*>(smem + (pdst[j] >= 0 ? pdst[j] : dummy_off)) = stage_transform<TIN, ACT>(raw[j], pmask[j], ca, cb);
     }
 
     typename MF::frag af[KSTEPS][TM], bf[KSTEPS][TN];
@@ -241,7 +223,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
                 _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);  \
         if ((T) >= 1 && (T) < PIECE_ITERS + 1) {             /* unconditional at run time: same basic block as the MFMAs */ \
             constexpr int k_ = (T) >= 1 && (T) < PIECE_ITERS + 1 ? (T)-1 : 0;                                        \
-            t0 = v4_transform<TIN, ACT>(hT, pmask[k_], ca, cb);                                                      \
+            t0 = stage_transform<TIN, ACT>(hT, pmask[k_], ca, cb);                                                      \
             asm volatile("" : "+v"(t0.x), "+v"(t0.y), "+v"(t0.z), "+v"(t0.w));   /* materialise here, not at the ds_write */ \
             _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                         \
                 __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * KSTEPS / 16, 0);   /* MFMA  */                 \
@@ -335,6 +317,16 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     const int ch = lane % CPR;
     const int co0 = n0 + ch * CH;
     const bool cok = co0 < p.Cout;
+    // Combine ('sum') weights of this lane's channels: loop-invariant, fetched once (they were re-read per pixel piece)
+    constexpr bool HOIST_W4 = sizeof(TOUT) == 2;             // fp32 parity kernels: no registers to spare, in-loop loads
+    float4 w4r[CH]; float b4r[CH];
+    if (HOIST_W4 && p.pyr && cok) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { w4r[c] = *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4); b4r[c] = p.b4[co0 + c]; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { w4r[c] = make_float4(0.f, 0.f, 0.f, 0.f); b4r[c] = 0.f; }
+    }
     float st_s[CH], st_q[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) { st_s[c] = 0.f; st_q[c] = 0.f; }
@@ -384,8 +376,8 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
                     const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
-                        const float4 wq = *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4);
-                        v[c] += p.b4[co0 + c] + wq.x * pq.x + wq.y * pq.y + wq.z * pq.z + wq.w * pq.w;
+                        const float4 wq = HOIST_W4 ? w4r[c] : *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4);
+                        v[c] += (HOIST_W4 ? b4r[c] : p.b4[co0 + c]) + wq.x * pq.x + wq.y * pq.y + wq.z * pq.z + wq.w * pq.w;
                     }
                 }
                 const uint4 packed = Vec16<TOUT>::pack(v);
@@ -486,8 +478,9 @@ void launch_conv_v4(const ConvArgs& a0, hipStream_t s) {
         }
     }
 #endif
-    if (a.in_dtype == DT_BF16) { a.act ? v4_launch_t<__bf16, __bf16, 32, true>(a, s) : v4_launch_t<__bf16, __bf16, 32, false>(a, s); }
-    else                       { a.act ? v4_launch_t<float, float, 16, true>(a, s) : v4_launch_t<float, float, 16, false>(a, s); }
+    if (a.in_dtype == DT_BF16)     { a.act ? v4_launch_t<__bf16, __bf16, 32, true>(a, s) : v4_launch_t<__bf16, __bf16, 32, false>(a, s); }
+    else if (a.in_dtype == DT_F16) { a.act ? v4_launch_t<_Float16, _Float16, 32, true>(a, s) : v4_launch_t<_Float16, _Float16, 32, false>(a, s); }
+    else                           { a.act ? v4_launch_t<float, float, 16, true>(a, s) : v4_launch_t<float, float, 16, false>(a, s); }
 }
 
 }  // namespace use

@@ -6,6 +6,7 @@
 namespace use {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -52,6 +53,44 @@ template <> struct Vec16<__bf16> {
     DEVI static void store(__bf16* p, const float (&v)[8]) { *reinterpret_cast<uint4*>(p) = pack(v); }
 };
 
+// GroupNorm affine (+ SiLU) of one 16-byte piece while it is staged into LDS: y = act(a*x + b) per channel, zeroed by
+// `mask` outside the image (the zero padding of the convolution applies AFTER the activation).
+template <typename TIN, bool ACT>
+DEVI uint4 stage_transform(const uint4 raw, const unsigned mask, const float (&ca)[16 / sizeof(TIN)],
+                           const float (&cb)[16 / sizeof(TIN)]) {
+    constexpr int VEC = 16 / sizeof(TIN);
+    float v[VEC];
+    Vec16<TIN>::load(reinterpret_cast<const TIN*>(&raw), v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        v[k] = fmaf(v[k], ca[k], cb[k]);
+        if (ACT) {
+            if (sizeof(TIN) == 4) v[k] = v[k] / (1.0f + expf(-v[k]));        // fp32 parity mode: accurate
+            else v[k] = v[k] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[k] * -1.44269504088896341f));
+        }
+    }
+    uint4 o = Vec16<TIN>::pack(v);
+    o.x &= mask; o.y &= mask; o.z &= mask; o.w &= mask;
+    return o;
+}
+
+template <> struct Vec16<_Float16> {
+    static constexpr int N = 8;
+    DEVI static void load(const _Float16* p, float (&v)[8]) {
+        uint4 u = *reinterpret_cast<const uint4*>(p);
+        f16x8 b = __builtin_bit_cast(f16x8, u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)b[i];
+    }
+    DEVI static uint4 pack(const float (&v)[8]) {
+        f16x8 b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = (_Float16)v[i];
+        return __builtin_bit_cast(uint4, b);
+    }
+    DEVI static void store(_Float16* p, const float (&v)[8]) { *reinterpret_cast<uint4*>(p) = pack(v); }
+};
+
 template <typename T> DEVI float to_f(T v) { return (float)v; }
 template <typename T> DEVI T from_f(float v) { return (T)v; }
 
@@ -65,6 +104,12 @@ template <> struct Mfma<__bf16> {
     typedef bf16x8 frag;
     DEVI static frag ld(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
     DEVI static f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma<_Float16> {
+    static constexpr int KM = 16, KPL = 8;
+    typedef f16x8 frag;
+    DEVI static frag ld(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
+    DEVI static f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct Mfma<float> {
     static constexpr int KM = 2, KPL = 1;

@@ -42,6 +42,28 @@ static inline uint16_t f32_to_bf16(float f) {   // round to nearest even
     return (uint16_t)(u >> 16);
 }
 
+static inline uint16_t f32_to_f16(float f) {    // round to nearest even, overflow -> inf, subnormals kept
+    uint32_t u; memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                 // NaN
+    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                // >= 65520 -> inf
+    if (u < 0x38800000u) {                                                  // subnormal half (or zero)
+        if (u < 0x33000000u) return (uint16_t)sign;
+        const int shift = 126 - (int)(u >> 23);                             // 14..24
+        uint32_t m = (u & 0x7fffffu) | 0x800000u;
+        const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1);
+        m >>= shift;
+        if (rest > half || (rest == half && (m & 1))) ++m;
+        return (uint16_t)(sign | m);
+    }
+    uint32_t v = u - 0x38000000u;                                           // rebias exponent
+    const uint32_t rest = v & 0x1fffu;
+    v >>= 13;
+    if (rest > 0x1000u || (rest == 0x1000u && (v & 1))) ++v;
+    return (uint16_t)(sign | v);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // architecture description
 // ---------------------------------------------------------------------------------------------------------
@@ -268,32 +290,37 @@ static int build_arch(use_handle* h) {
 // ---------------------------------------------------------------------------------------------------------
 // weight packing
 // ---------------------------------------------------------------------------------------------------------
-static void pack_conv(const use_handle* h, const ConvW& w, char* blob) {
-    const std::vector<float>& src = h->host_w.at(w.wname);
-    const std::vector<float>& bias = h->host_w.at(w.bname);
+// host float weights -> device layouts: dst [cout_pad][tap][cin] (see use_kernels.h) and, when dstb != null, the slab-major
+// copy [tap][chunk][cout_pad][ck] with piece-swizzled 64-byte rows (ConvArgs::wb)
+static void pack_conv_raw(const float* src, const ConvW& w, char* dst, char* dstb) {
     const size_t es = dtype_size(w.w_dtype);
-    char* dst = blob + w.w_off;
+    auto put = [&](char* base, size_t o, float v) {
+        if (w.w_dtype == DT_F32) ((float*)base)[o] = v;
+        else ((uint16_t*)base)[o] = w.w_dtype == DT_F16 ? f32_to_f16(v) : f32_to_bf16(v);
+    };
     memset(dst, 0, (size_t)w.ntaps * w.cout_pad * w.cin * es);
     for (int tap = 0; tap < w.ntaps; ++tap)
         for (int co = 0; co < w.cout_src; ++co)
             for (int ci = 0; ci < w.cin_src; ++ci) {
                 // reference conv weight [cout][cin][kh][kw]; NIN W is [cin][cout] (layers.py:639-650)
                 const float v = w.nin ? src[(size_t)ci * w.cout + co] : src[((size_t)co * w.cin_src + ci) * w.ntaps + tap];
-                const size_t o = ((size_t)co * w.ntaps + tap) * w.cin + ci;   // [cout][tap][cin]: see use_kernels.h
-                if (w.w_dtype == DT_F32) ((float*)dst)[o] = v; else ((uint16_t*)dst)[o] = f32_to_bf16(v);
+                put(dst, ((size_t)co * w.ntaps + tap) * w.cin + ci, v);       // [cout][tap][cin]: see use_kernels.h
             }
-    if (w.has_wb) {                                           // [tap][chunk][cout_pad][ck]: one (tap, chunk) slab contiguous
+    if (dstb) {                                               // [tap][chunk][cout_pad][ck]: one (tap, chunk) slab contiguous
         const int ck = conv_v4_chunk(w.w_dtype), nchunks = w.cin / ck;
-        char* dstb = blob + w.wb_off;
         memset(dstb, 0, (size_t)w.ntaps * w.cout_pad * w.cin * es);
         for (int tap = 0; tap < w.ntaps; ++tap)
             for (int co = 0; co < w.cout_src; ++co)
                 for (int ci = 0; ci < w.cin_src; ++ci) {
                     const float v = src[((size_t)co * w.cin_src + ci) * w.ntaps + tap];
-                    const size_t o = (((size_t)tap * nchunks + ci / ck) * w.cout_pad + co) * ck + ci % ck;
-                    if (w.w_dtype == DT_F32) ((float*)dstb)[o] = v; else ((uint16_t*)dstb)[o] = f32_to_bf16(v);
+                    const int vec = 16 / (int)es, e = ci % ck;             // 64-byte rows, 16-byte pieces swizzled by the row
+                    put(dstb, (((size_t)tap * nchunks + ci / ck) * w.cout_pad + co) * ck + (((e / vec) ^ ((co >> 2) & 3)) * vec + e % vec), v);
                 }
     }
+}
+static void pack_conv(const use_handle* h, const ConvW& w, char* blob) {
+    const std::vector<float>& bias = h->host_w.at(w.bname);
+    pack_conv_raw(h->host_w.at(w.wname).data(), w, blob + w.w_off, w.has_wb ? blob + w.wb_off : nullptr);
     memset(blob + w.b_off, 0, (size_t)w.cout * 4);
     memcpy(blob + w.b_off, bias.data(), (size_t)w.cout_src * 4);
 }
@@ -460,7 +487,7 @@ struct Fwd {
         Act v = conv(x, nullptr, coef, 0, aw.v, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
         Act a = new_act(x.C, x.H, x.W, dt, false);
         const int N = x.H * x.W;
-        const int ck = dt == DT_BF16 ? 64 : 32;
+        const int ck = dt == DT_F32 ? 32 : 64;
         if (N > 512 && N % 128 == 0 && x.C % 128 == 0 && N % ck == 0) {
             // long sequences (64x80 bottleneck of the refine generator): per batch item two implicit GEMMs on conv_kernel.
             // The key tensor [N][C] already is a packed 1x1 weight [Cout = N][1][Cin = C]; v^T plays that part for P.V
@@ -706,6 +733,8 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "subbatch")) { g_subbatch = (int)value; return USE_OK; }          // takes effect at the next use_plan
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
+    if (!strcmp(name, "conv_v5_min_blocks")) { conv_v5_set_min_blocks((long)value); return USE_OK; }
+    if (!strcmp(name, "conv_v5_stagger")) { conv_v5_set_stagger((int)value); return USE_OK; }
     return fail(USE_E_INVALID, "unknown option '%s'", name);
 }
 const char* use_last_error(void) { return g_err.c_str(); }
@@ -717,12 +746,12 @@ int use_create(const use_config* cfg, int device, use_handle** out) {
         return fail(USE_E_INVALID, "unsupported architecture (nf must be a multiple of 64, 1..8 levels)");
     if (cfg->n_freq % (1 << (cfg->n_levels - 1)) != 0)
         return fail(USE_E_INVALID, "n_freq=%d is not divisible by 2^(levels-1)", cfg->n_freq);
-    if (cfg->precision != USE_PREC_FP32 && cfg->precision != USE_PREC_BF16) return fail(USE_E_INVALID, "bad precision");
+    if (cfg->precision != USE_PREC_FP32 && cfg->precision != USE_PREC_BF16 && cfg->precision != USE_PREC_FP16) return fail(USE_E_INVALID, "bad precision");
     if (cfg->input_channels != 0 && cfg->input_channels != 2 && cfg->input_channels != 4)
         return fail(USE_E_INVALID, "input_channels must be 4 (x and y) or 2 (y alone), got %d", cfg->input_channels);
     use_handle* h = new use_handle();
     h->cfg = *cfg; h->device = device;
-    h->act_dtype = cfg->precision == USE_PREC_BF16 ? DT_BF16 : DT_F32;
+    h->act_dtype = cfg->precision == USE_PREC_BF16 ? DT_BF16 : cfg->precision == USE_PREC_FP16 ? DT_F16 : DT_F32;
     int rc = build_arch(h);
     if (rc) { delete h; return rc; }
     *out = h;
@@ -806,7 +835,7 @@ int use_commit_weights(use_handle* h) {
 // ---- packed weight file: header + the device blob, so that a deployment starts without a state dict ------
 // The blob layout is private to a library build: BLOB_LAYOUT is bumped whenever pack_all / the blob offsets change.
 namespace {
-constexpr uint32_t BLOB_LAYOUT = 3;          // 3: second, slab-major copy of the 3x3 / shortcut weights (conv_v4_kernel)
+constexpr uint32_t BLOB_LAYOUT = 4;          // 4: slab-major copy of the 3x3 / shortcut weights with piece-swizzled 64-byte rows
 struct BlobHeader {
     char magic[8];                           // "USEHIPWB"
     uint32_t header_bytes, layout;
@@ -1160,6 +1189,142 @@ int use_sde_corrector(use_handle* h, int corrector, float t, float snr, int B, c
     } else return fail(USE_E_INVALID, "corrector id %d has no update kernel", corrector);
     HIPCHK(hipGetLastError());
     return USE_OK;
+}
+
+// ---- single-convolution harness (kernel bring-up / A-B timing; no reference counterpart) ----------------------------------
+namespace {
+__global__ void fill_uniform_kernel(void* p, size_t n, int dtype, unsigned seed, float lo, float hi) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + ((unsigned long long)seed << 32 | 0x1234567u);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    const float v = lo + (hi - lo) * (float)((z >> 40) * (1.0 / 16777216.0));
+    if (dtype == DT_F32) ((float*)p)[i] = v;
+    else if (dtype == DT_BF16) ((__bf16*)p)[i] = (__bf16)v;
+    else ((_Float16*)p)[i] = (_Float16)v;
+}
+__global__ void to_float_kernel(const void* p, float* out, size_t n, int dtype) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = dtype == DT_F32 ? ((const float*)p)[i] : dtype == DT_BF16 ? (float)((const __bf16*)p)[i] : (float)((const _Float16*)p)[i];
+}
+}  // namespace
+
+int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, double* ms_avg, double* flops) {
+    if (!c || c->B < 1 || c->H < 1 || c->W < 1 || c->C0 < 1 || c->Cout < 1) return fail(USE_E_INVALID, "bad conv case");
+    const int dt = c->dtype;
+    if (dt != DT_F32 && dt != DT_BF16 && dt != DT_F16) return fail(USE_E_INVALID, "bad dtype");
+    const size_t es = dtype_size(dt);
+    const int Cin = c->C0 + c->C1, XC = c->XC0 + c->XC1;
+    const size_t px = (size_t)c->B * c->H * c->W;
+    std::vector<void*> bufs;
+    auto dalloc = [&](size_t bytes) -> void* { void* q = nullptr; if (hipMalloc(&q, bytes) != hipSuccess) return nullptr; bufs.push_back(q); return q; };
+    auto cleanup = [&]() { for (void* q : bufs) (void)hipFree(q); };
+    auto fill = [&](void* q, size_t n, int dtype, unsigned seed, float lo, float hi) {
+        hipLaunchKernelGGL(fill_uniform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, q, n, dtype, seed, lo, hi);
+    };
+    ConvW w; w.cin = Cin; w.cout = c->Cout; w.ntaps = 9; w.w_dtype = dt; w.cin_src = Cin; w.cout_src = c->Cout;
+    w.cout_pad = c->Cout <= 32 ? 32 : (c->Cout + 127) / 128 * 128;
+    ConvW w2 = w; w2.cin = XC; w2.cin_src = XC; w2.ntaps = 1;
+    ConvArgs a{};
+    a.B = c->B; a.H = c->H; a.W = c->W; a.Cout = c->Cout; a.ntaps = 9; a.in_dtype = dt; a.out_dtype = dt;
+    a.C0 = c->C0; a.C1 = c->C1; a.XC0 = c->XC0; a.XC1 = c->XC1; a.act = c->act; a.out_scale = c->res || XC ? 0.70710678f : 1.f;
+    a.cout_pad = w.cout_pad;
+    void* src0 = dalloc(px * c->C0 * es); void* src1 = c->C1 ? dalloc(px * c->C1 * es) : nullptr;
+    void* x0 = c->XC0 ? dalloc(px * c->XC0 * es) : nullptr; void* x1 = c->XC1 ? dalloc(px * c->XC1 * es) : nullptr;
+    void* res = c->res ? dalloc(px * c->Cout * es) : nullptr;
+    void* out = dalloc(px * c->Cout * es);
+    float* outf = (float*)dalloc(px * c->Cout * 4);
+    float* coef = c->gn ? (float*)dalloc((size_t)c->B * Cin * 2 * 4) : nullptr;
+    float* bias = (float*)dalloc((size_t)c->Cout * 4); float* temb = (float*)dalloc((size_t)c->B * c->Cout * 4);
+    const size_t wbytes = (size_t)9 * w.cout_pad * Cin * es, w2bytes = (size_t)w2.cout_pad * std::max(XC, 1) * es;
+    char* dw = (char*)dalloc(wbytes); char* dwb = (char*)dalloc(wbytes);
+    char* dw2 = XC ? (char*)dalloc(w2bytes) : nullptr; char* dw2b = XC ? (char*)dalloc(w2bytes) : nullptr;
+    const int max_tiles = tiles_per_image(c->H, c->W);       // the finest tiling any kernel uses
+    float* stats = c->stats ? (float*)dalloc((size_t)c->B * max_tiles * c->Cout * 2 * 4) : nullptr;
+    if (!src0 || !out || !outf || !dw || !dwb || (c->stats && !stats)) { cleanup(); return fail(USE_E_NOMEM, "conv bench allocation failed"); }
+    fill(src0, px * c->C0, dt, 1, -2.f, 2.f); if (src1) fill(src1, px * c->C1, dt, 2, -2.f, 2.f);
+    if (x0) fill(x0, px * c->XC0, dt, 3, -1.f, 1.f); if (x1) fill(x1, px * c->XC1, dt, 4, -1.f, 1.f);
+    if (res) fill(res, px * c->Cout, dt, 5, -1.f, 1.f);
+    if (coef) fill(coef, (size_t)c->B * Cin * 2, DT_F32, 6, -0.9f, 1.1f);
+    fill(bias, c->Cout, DT_F32, 7, -0.5f, 0.5f); fill(temb, (size_t)c->B * c->Cout, DT_F32, 8, -0.5f, 0.5f);
+    {
+        std::vector<float> hw((size_t)c->Cout * Cin * 9), hw2((size_t)c->Cout * std::max(XC, 1));
+        unsigned long long st = 88172645463325252ull;
+        auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (float)((st >> 40) * (1.0 / 16777216.0)) * 2.f - 1.f; };
+        const float sc = 1.0f / std::sqrt((float)Cin * 9.f / 3.f);
+        for (auto& v : hw) v = rnd() * sc;
+        for (auto& v : hw2) v = rnd() * (1.0f / std::sqrt((float)std::max(XC, 1) / 3.f));
+        std::vector<char> hp(wbytes), hpb(wbytes);
+        const bool slab = w.cout_pad % 128 == 0 && Cin % conv_v4_chunk(dt) == 0;
+        pack_conv_raw(hw.data(), w, hp.data(), slab ? hpb.data() : nullptr);
+        (void)hipMemcpy(dw, hp.data(), wbytes, hipMemcpyHostToDevice);
+        if (slab) (void)hipMemcpy(dwb, hpb.data(), wbytes, hipMemcpyHostToDevice);
+        a.w = dw; a.wb = slab ? dwb : nullptr;
+        if (XC) {
+            std::vector<char> hq(w2bytes), hqb(w2bytes);
+            const bool slab2 = XC % conv_v4_chunk(dt) == 0 && w2.cout_pad % 128 == 0;
+            pack_conv_raw(hw2.data(), w2, hq.data(), slab2 ? hqb.data() : nullptr);
+            (void)hipMemcpy(dw2, hq.data(), w2bytes, hipMemcpyHostToDevice);
+            if (slab2) (void)hipMemcpy(dw2b, hqb.data(), w2bytes, hipMemcpyHostToDevice);
+            a.w2 = dw2; a.w2b = slab2 ? dw2b : nullptr;
+        }
+    }
+    a.src0 = src0; a.src1 = src1; a.x0 = x0; a.x1 = x1; a.coef = coef; a.bias = bias; a.temb = c->temb ? temb : nullptr;
+    a.temb_bstride = c->Cout; a.res = res; a.out = out; a.stats = stats;
+    auto run = [&]() -> int {
+        switch (c->variant) {
+            case 0: launch_conv(a, 0); return 0;
+            case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
+            case 4: if (!a.wb || (XC && !a.w2b)) return -1; launch_conv_v4(a, 0); return 0;
+            case 5: if (!a.wb || (XC && !a.w2b) || dt == DT_F32) return -1; launch_conv_v5(a, 0); return 0;
+            default: return -1;
+        }
+    };
+    if (getenv("USE_HIP_DBG")) a.dbg = atoi(getenv("USE_HIP_DBG"));     // ablation bits (USE_HIP_ABLATE kernels)
+    unsigned long long* trace = nullptr;
+    if (getenv("USE_HIP_TRACE")) {                            // bring-up (USE_HIP_TRACE_BUILD kernels): stamps of workgroup $USE_HIP_TRACE
+        trace = (unsigned long long*)dalloc(512 * 8);
+        if (trace) { (void)hipMemset(trace, 0, 512 * 8); a.trace = trace; a.dbg = atoi(getenv("USE_HIP_TRACE")); }
+    }
+    if (stats) (void)hipMemset(stats, 0, (size_t)c->B * max_tiles * c->Cout * 2 * 4);
+    if (run() != 0) { cleanup(); return fail(USE_E_INVALID, "variant %d cannot run this case", c->variant); }
+    if (hipDeviceSynchronize() != hipSuccess) { cleanup(); return fail(USE_E_HIP, "conv bench: launch failed: %s", hipGetErrorString(hipGetLastError())); }
+    if (trace) {
+        unsigned long long hb[512];
+        (void)hipMemcpy(hb, trace, sizeof hb, hipMemcpyDeviceToHost);
+        unsigned long long prev = hb[1];
+        for (int i = 0; i < 250 && hb[2 * i]; ++i) { fprintf(stderr, "[trace] id %3llu  +%6llu\n", hb[2 * i], hb[2 * i + 1] - prev); prev = hb[2 * i + 1]; }
+        a.trace = nullptr;
+    }
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int iters = std::max(1, c->iters);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) run();
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms_avg) *ms_avg = ms / iters;
+    if (flops) *flops = 2.0 * (double)px * c->Cout * ((double)Cin * 9 + XC);
+    int rc = USE_OK;
+    if (out_host) {
+        hipLaunchKernelGGL(to_float_kernel, dim3((unsigned)((px * c->Cout + 255) / 256)), dim3(256), 0, 0, out, outf, px * c->Cout, dt);
+        if (hipMemcpy(out_host, outf, px * c->Cout * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(USE_E_HIP, "copy back failed");
+    }
+    if (stats_host && stats) {                                // per (item, channel) totals: sum over the kernel's tiles
+        const int nt = c->variant == 0 ? conv_out_tiles(a) : c->variant == 5 ? conv_v5_tiles(c->H, c->W) : c->variant == 4 ? conv_v4_tiles(c->H, c->W) : conv_v2_tiles(c->H, c->W);
+        std::vector<float> hs((size_t)c->B * nt * c->Cout * 2);
+        if (hipMemcpy(hs.data(), stats, hs.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(USE_E_HIP, "copy back failed");
+        for (int b = 0; b < c->B; ++b)
+            for (int co = 0; co < c->Cout; ++co) {
+                double s0 = 0, s1 = 0;
+                for (int t = 0; t < nt; ++t) { s0 += hs[(((size_t)b * nt + t) * c->Cout + co) * 2]; s1 += hs[(((size_t)b * nt + t) * c->Cout + co) * 2 + 1]; }
+                stats_host[((size_t)b * c->Cout + co) * 2] = (float)s0; stats_host[((size_t)b * c->Cout + co) * 2 + 1] = (float)s1;
+            }
+    }
+    cleanup();
+    return rc;
 }
 
 int use_debug_tensor(use_handle* h, const char* name, void** dev_ptr, int* dims4, int* dtype) {

@@ -6,7 +6,7 @@
 
 namespace use {
 
-enum DType { DT_F32 = 0, DT_BF16 = 1 };
+enum DType { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 
 constexpr int TILE_H = 8;    // conv output tile: 8 x 16 pixels = 128 GEMM rows
@@ -26,7 +26,9 @@ struct ConvArgs {
     int act;                // 0: none, 1: SiLU (after the affine)
     const void* w;          // packed [CoutPad][ntaps][C0+C1] in in_dtype
     const void* wb;         // optional slab-major copy [ntaps][(C0+C1)/ck][CoutPad][ck], ck = conv_v4_chunk(in_dtype)
-                            // (one (tap, chunk) slab contiguous: conv_v4_kernel), or null
+                            // (one (tap, chunk) slab contiguous: conv_v4 / conv_v5), or null.  Rows are 64 bytes; the 16-byte
+                            // piece q of row n is stored at position q ^ ((n >> 2) & 3) (bank-conflict-free LDS image for
+                            // a lane-linear LDS-DMA copy, see use_conv_v5.hip)
     int cout_pad;
     // optional second K segment: + conv1x1(concat(x0[XC0], x1[XC1])) with weights w2 [CoutPad][1][XC0+XC1]
     // (the res-block shortcut Conv_2 fused into Conv_1; raw input, no affine / activation)
@@ -43,6 +45,7 @@ struct ConvArgs {
     void* out; int out_dtype;
     float* stats;           // or null
     int B, H, W, Cout, ntaps;
+    int stagger, stagger_lo, stagger_hi;   // conv_v5_kernel: workgroups [lo, hi) of the dispatch order start `stagger` x s_sleep(127) late
     int dbg;                // ablation bits for kernel bring-up (0 in production)
     unsigned long long* trace;   // optional: s_memtime stamps of workgroup 0 (kernel bring-up), else null
 };
@@ -51,14 +54,21 @@ void launch_conv(const ConvArgs& a, hipStream_t s);
 bool conv_v2_eligible(const ConvArgs& a);
 void launch_conv_v2(const ConvArgs& a, hipStream_t s);
 // wide-tile variant (use_conv_v4.hip): 16x32-pixel tiles, K chunks of conv_v4_chunk() channels, slab-major weights
-inline int conv_v4_chunk(int dtype) { return dtype == DT_BF16 ? 32 : 16; }
+inline int conv_v4_chunk(int dtype) { return dtype == DT_F32 ? 16 : 32; }
 inline int conv_v4_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 31) / 32); }
+// two-workgroups-per-CU variant for 16-bit storage (use_conv_v5.hip): 8x32-pixel tiles, weights by LDS-DMA from the
+// swizzled slab-major copy
+inline int conv_v5_tiles(int H, int W) { return ((H + 7) / 8) * ((W + 31) / 32); }
+bool conv_v5_eligible(const ConvArgs& a);
+void conv_v5_set_min_blocks(long n);                     // smallest per-image grid conv_v5 is used for
+void conv_v5_set_stagger(int n);                         // -1: automatic, 0: off, n: delay of the second resident workgroups
+void launch_conv_v5(const ConvArgs& a, hipStream_t s);
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 128 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);
 // number of per-image statistics tiles the kernel chosen for `a` writes (stats layout [B][tiles][Cout][2])
 inline int conv_out_tiles(const ConvArgs& a) {
-    return conv_v4_eligible(a) ? conv_v4_tiles(a.H, a.W) : conv_v2_eligible(a) ? conv_v2_tiles(a.H, a.W) : tiles_per_image(a.H, a.W);
+    return conv_v5_eligible(a) ? conv_v5_tiles(a.H, a.W) : conv_v4_eligible(a) ? conv_v4_tiles(a.H, a.W) : conv_v2_eligible(a) ? conv_v2_tiles(a.H, a.W) : tiles_per_image(a.H, a.W);
 }
 
 // GroupNorm finalisation: per-(b, group) mean / rstd from per-tile per-channel partial sums of up to

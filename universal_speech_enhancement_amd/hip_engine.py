@@ -258,6 +258,8 @@ class HipScoreEngine:
         raw = torch.as_tensor(o, device=f"cuda:{self.device}").clone()
         if dt.value == 1:
             raw = raw.view(torch.bfloat16)
+        elif dt.value == 2:
+            raw = raw.view(torch.float16)
         return raw.float().view(*dims[:])
 
     # ---- stand-alone SDE element-wise updates (use_sde_*) ----------------------------------------------
