@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = addv[j];   // bias + time-embedding bias: the sum starts there
 
     int a_base[TM], b_base[TN];                              // LDS byte offsets of this lane's fragments
 #pragma unroll
@@ -305,20 +305,31 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
 #undef V4_STORE_W
 
     // ------------------------------ epilogue: per-wave LDS transpose, 16-byte I/O ------------------------------------------
+    // VALU diet (the epilogue used to be 47 % of the kernel's VALU instructions, all of them outside the MFMAs' shadow):
+    // every global access is a buffer load / store with a 32-bit offset = lane-constant part + wave-uniform part (no
+    // per-pass 64-bit address arithmetic; tiles are always full here: H % 16 == 0, W % 32 == 0), the bias already sits in
+    // the accumulators, the multiply by out_scale is skipped when it is 1, and the GroupNorm partial sums are taken from the
+    // fp32 values (of which the stored ones are the roundings) instead of re-expanding the packed result.
     constexpr int STG_LD = BN + 4;
     constexpr int STG_WAVE = 32 * STG_LD * 4;                // 16,896 B per wave and round
     constexpr int CH = 16 / (int)sizeof(TOUT);
     constexpr int CPR = BN / CH;                             // 16-byte chunks per pixel row: 16 (bf16) / 32 (fp32)
     constexpr int QN = 32 * CPR / 64;                        // passes per round: 8 / 16
+    constexpr int PPP = 64 / CPR;                            // pixels per pass: 4 / 2
     float* const stg = reinterpret_cast<float*>(smem + wave * STG_WAVE);
     float* const red = reinterpret_cast<float*>(smem + 8 * STG_WAVE);     // [8 waves][BN][2]
-    TOUT* out = (TOUT*)p.out;
-    const TOUT* res = (const TOUT*)p.res;
     const int ch = lane % CPR;
     const int co0 = n0 + ch * CH;
     const bool cok = co0 < p.Cout;
-    // Combine ('sum') weights of this lane's channels: loop-invariant, fetched once (they were re-read per pixel piece)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // provably uniform: the soffsets below must live in SGPRs
+    const size_t img_elems = (size_t)p.H * p.W * p.Cout;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((TOUT*)p.out + (size_t)b * img_elems, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<TOUT*>((const TOUT*)p.res) + (size_t)b * img_elems, 0, 0x7fffffff, 0x00020000);
+    const unsigned voff = cok ? (unsigned)(((lane / CPR) * p.Cout + co0) * (int)sizeof(TOUT)) : 0u;
+    const unsigned pass_b = (unsigned)(PPP * p.Cout) * (unsigned)sizeof(TOUT);      // bytes between passes
+    const bool has_res = p.res != nullptr, has_scale = p.out_scale != 1.f;
     constexpr bool HOIST_W4 = sizeof(TOUT) == 2;             // fp32 parity kernels: no registers to spare, in-loop loads
+    // Combine ('sum') weights of this lane's channels: loop-invariant, fetched once (they were re-read per pixel piece)
     float4 w4r[CH]; float b4r[CH];
     if (HOIST_W4 && p.pyr && cok) {
 #pragma unroll
@@ -332,62 +343,59 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     for (int c = 0; c < CH; ++c) { st_s[c] = 0.f; st_q[c] = 0.f; }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int gy = ty0 + wave * 2 + i;                   // this round's tile row
+        const int gy = ty0 + wave_u * 2 + i;                 // this round's tile row (uniform)
+        const unsigned row_b = (unsigned)((gy * p.W + tx0) * p.Cout) * (unsigned)sizeof(TOUT);
         // residual pieces of this round are fetched before the transposition (their latency overlaps it)
         uint4 resv[QN];
-        if (res) {
+        if (has_res) {
 #pragma unroll
-            for (int q = 0; q < QN; ++q) {
-                const int gx = tx0 + (q * 64 + lane) / CPR;
-                const bool ok = cok && gy < p.H && gx < p.W;
-                const size_t pix = ok ? (size_t)(b * p.H + gy) * p.W + gx : 0;
-                resv[q] = *reinterpret_cast<const uint4*>(res + pix * p.Cout + (ok ? co0 : 0));
-            }
+            for (int q = 0; q < QN; ++q)
+                resv[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff + row_b + (unsigned)q * pass_b, 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                stg[row * STG_LD + j * 32 + (lane & 31)] = acc[i][j][r] + addv[j];
+                stg[row * STG_LD + j * 32 + (lane & 31)] = acc[i][j][r];
             }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
             const int row = (q * 64 + lane) / CPR;           // pixel column inside the tile row
-            const int gx = tx0 + row;
             float v[CH];
 #pragma unroll
             for (int c4 = 0; c4 < CH / 4; ++c4) {
                 const float4 t4 = *reinterpret_cast<const float4*>(stg + row * STG_LD + ch * CH + c4 * 4);
                 v[c4 * 4] = t4.x; v[c4 * 4 + 1] = t4.y; v[c4 * 4 + 2] = t4.z; v[c4 * 4 + 3] = t4.w;
             }
-            if (cok && gy < p.H && gx < p.W) {
-                const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
-                if (res) {
-                    float rv[CH];
-                    Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&resv[q]), rv);
+            if (has_res) {
+                float rv[CH];
+                Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&resv[q]), rv);
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) v[c] += rv[c];
-                }
+                for (int c = 0; c < CH; ++c) v[c] += rv[c];
+            }
+            if (has_scale) {
 #pragma unroll
                 for (int c = 0; c < CH; ++c) v[c] *= p.out_scale;
-                if (p.pyr) {
-                    const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
+            }
+            if (p.pyr) {
+                const size_t pix = (size_t)(b * p.H + gy) * p.W + tx0 + row;
+                const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        const float4 wq = HOIST_W4 ? w4r[c] : *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4);
-                        v[c] += (HOIST_W4 ? b4r[c] : p.b4[co0 + c]) + wq.x * pq.x + wq.y * pq.y + wq.z * pq.z + wq.w * pq.w;
-                    }
+                for (int c = 0; c < CH; ++c) {
+                    const float4 wq = HOIST_W4 ? w4r[c] : (cok ? *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
+                    v[c] += (HOIST_W4 ? b4r[c] : (cok ? p.b4[co0 + c] : 0.f)) + wq.x * pq.x + wq.y * pq.y + wq.z * pq.z + wq.w * pq.w;
                 }
+            }
+            if (cok) {
                 const uint4 packed = Vec16<TOUT>::pack(v);
-                *reinterpret_cast<uint4*>(out + pix * p.Cout + co0) = packed;
-                if (p.stats) {
-                    float vr[CH];
-                    Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&packed), vr);
+                // (voffset carries the whole offset: with the uniform part in soffset, hipcc 7.2 mis-assigns the SGPR of one pass in
+                // the 16-pass fp32 instantiation - one VALU add per pass is the price of not depending on that)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, packed), rs_out,
+                                                       voff + row_b + (unsigned)q * pass_b, 0, 0);
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) { st_s[c] += vr[c]; st_q[c] += vr[c] * vr[c]; }
-                }
+                for (int c = 0; c < CH; ++c) { st_s[c] += v[c]; st_q[c] = fmaf(v[c], v[c], st_q[c]); }
             }
         }
         __builtin_amdgcn_wave_barrier();
