@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuse_hip.so")
+LIB_PATH = os.environ.get("USE_HIP_LIB") or os.path.join(_HERE, "libuse_hip.so")   # USE_HIP_LIB: same-box A/B of two builds
 
 PREC = {"fp32": 0, "bf16": 1, "fp16": 2}
 PREDICTORS = {"reverse_diffusion": 0, "euler_maruyama": 1, "none": 2}
@@ -87,6 +87,8 @@ def lib() -> C.CDLL:
                 "There is no CPU fallback for the sampling path.")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if os.environ.get("USE_HIP_LIB") and not hasattr(L, name):
+                continue               # an older build under A/B test may lack the newest entry points
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
         _lib = L

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = addv[j];   // bias + time-embedding bias: the sum starts there
 
     int a_base[TM], b_base[TN];                              // LDS byte offsets of this lane's fragments
 #pragma unroll
@@ -361,19 +361,26 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
 #undef V2_STORE_W
 
     V2_STAMP(4)
-    // ------------------------------ epilogue (as conv_kernel: per-wave LDS transpose, 16-byte I/O) -------------------
+    // ------------------------------ epilogue: per-wave LDS transpose, 16-byte I/O -------------------------------------------
+    // Same VALU diet as conv_v4's epilogue: 32-bit buffer offsets (lane-constant part + uniform part), the bias already in
+    // the accumulators, out_scale skipped when it is 1, GroupNorm partial sums from the fp32 values.
     constexpr int STG_LD = NW + 4;
     constexpr int STG_WAVE = 32 * STG_LD * 4;
     constexpr int CH = 16 / (int)sizeof(TOUT);
     constexpr int CPR = NW / CH;
     constexpr int QN = 32 * CPR / 64;
+    constexpr int PPP = 64 / CPR;                            // pixels per pass (8 / 4): a pass never straddles a 16-pixel tile row
     float* const stg = reinterpret_cast<float*>(smem + wave * STG_WAVE);
     float* const red = reinterpret_cast<float*>(smem + 8 * STG_WAVE);     // [WM][BN][2]
-    TOUT* out = (TOUT*)p.out;
-    const TOUT* res = (const TOUT*)p.res;
-    const int ch = lane % CPR;
+    const int ch = lane % CPR, lx = lane / CPR;
     const int co0 = n0 + wn * NW + ch * CH;
     const bool cok = co0 < p.Cout;
+    const int wm_u = __builtin_amdgcn_readfirstlane(wm);
+    const size_t img_elems = (size_t)p.H * p.W * p.Cout;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((TOUT*)p.out + (size_t)b * img_elems, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<TOUT*>((const TOUT*)p.res) + (size_t)b * img_elems, 0, 0x7fffffff, 0x00020000);
+    const unsigned voff = (unsigned)((lx * p.Cout + co0) * (int)sizeof(TOUT));
+    const bool has_res = p.res != nullptr, has_scale = p.out_scale != 1.f;
     // Combine ('sum') weights of this lane's channels: loop-invariant, fetched once (they were re-read per pixel piece)
     constexpr bool HOIST_W4 = sizeof(TOUT) == 2;             // fp32 parity kernels: no registers to spare, in-loop loads
     float4 w4r[CH]; float b4r[CH];
@@ -387,19 +394,21 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
     float st_s[CH], st_q[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) { st_s[c] = 0.f; st_q[c] = 0.f; }
+    // pixel of pass q of round i: tile row trow (uniform), tile column tcol0 + lx
+#define V2_EPI_POS(I, Q)                                                                                             \
+        const int m0_ = wm_u * MW + (I)*32 + (Q)*PPP;                                                                \
+        const int gy = ty0 + (m0_ >> 4), gx = tx0 + (m0_ & 15) + lx;                                                 \
+        const bool ok = cok && gy < p.H && gx < p.W;                                                                 \
+        const unsigned off = ok ? voff + (unsigned)((gy * p.W + tx0 + (m0_ & 15)) * p.Cout) * (unsigned)sizeof(TOUT) : 0u;
     // residual pieces of both staging rounds are fetched up front (their HBM latency overlaps the LDS transposes)
     uint4 resv[TM][QN];
-    if (res) {
+    if (has_res) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int q = 0; q < QN; ++q) {
-                const int row = (q * 64 + lane) / CPR;
-                const int m = wm * MW + i * 32 + row;
-                const int gy = ty0 + (m >> 4), gx = tx0 + (m & 15);
-                const bool ok = cok && gy < p.H && gx < p.W;
-                const size_t pix = ok ? (size_t)(b * p.H + gy) * p.W + gx : 0;
-                resv[i][q] = *reinterpret_cast<const uint4*>(res + pix * p.Cout + (ok ? co0 : 0));
+                V2_EPI_POS(i, q)
+                resv[i][q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0));
             }
     }
 #pragma unroll
@@ -409,52 +418,50 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                stg[row * STG_LD + j * 32 + (lane & 31)] = acc[i][j][r] + addv[j];
+                stg[row * STG_LD + j * 32 + (lane & 31)] = acc[i][j][r];
             }
         __builtin_amdgcn_wave_barrier();
         V2_STAMP(41 + 2 * i)
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
             const int row = (q * 64 + lane) / CPR;
-            const int m = wm * MW + i * 32 + row;
-            const int gy = ty0 + (m >> 4), gx = tx0 + (m & 15);
+            V2_EPI_POS(i, q)
             float v[CH];
 #pragma unroll
             for (int c4 = 0; c4 < CH / 4; ++c4) {
                 const float4 t4 = *reinterpret_cast<const float4*>(stg + row * STG_LD + ch * CH + c4 * 4);
                 v[c4 * 4] = t4.x; v[c4 * 4 + 1] = t4.y; v[c4 * 4 + 2] = t4.z; v[c4 * 4 + 3] = t4.w;
             }
-            if (cok && gy < p.H && gx < p.W) {
-                const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
-                if (res) {
-                    float rv[CH];
-                    Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&resv[i][q]), rv);
+            if (has_res) {
+                float rv[CH];
+                Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&resv[i][q]), rv);
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) v[c] += rv[c];
-                }
+                for (int c = 0; c < CH; ++c) v[c] += rv[c];
+            }
+            if (has_scale) {
 #pragma unroll
                 for (int c = 0; c < CH; ++c) v[c] *= p.out_scale;
-                if (p.pyr) {
-                    const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
+            }
+            if (p.pyr && ok) {
+                const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+                const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        const float4 wq = HOIST_W4 ? w4r[c] : *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4);
-                        v[c] += (HOIST_W4 ? b4r[c] : p.b4[co0 + c]) + wq.x * pq.x + wq.y * pq.y + wq.z * pq.z + wq.w * pq.w;
-                    }
+                for (int c = 0; c < CH; ++c) {
+                    const float4 wq = HOIST_W4 ? w4r[c] : *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4);
+                    v[c] += (HOIST_W4 ? b4r[c] : p.b4[co0 + c]) + wq.x * pq.x + wq.y * pq.y + wq.z * pq.z + wq.w * pq.w;
                 }
+            }
+            if (ok) {
                 const uint4 packed = Vec16<TOUT>::pack(v);
-                *reinterpret_cast<uint4*>(out + pix * p.Cout + co0) = packed;
-                if (p.stats) {
-                    float vr[CH];
-                    Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&packed), vr);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, packed), rs_out, off, 0, 0);
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) { st_s[c] += vr[c]; st_q[c] += vr[c] * vr[c]; }
-                }
+                for (int c = 0; c < CH; ++c) { st_s[c] += v[c]; st_q[c] = fmaf(v[c], v[c], st_q[c]); }
             }
         }
         __builtin_amdgcn_wave_barrier();
         V2_STAMP(42 + 2 * i)
     }
+#undef V2_EPI_POS
     if (p.stats) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) { st_s[c] = reduce_lanes_stride<CPR>(st_s[c]); st_q[c] = reduce_lanes_stride<CPR>(st_q[c]); }

@@ -733,8 +733,11 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "subbatch")) { g_subbatch = (int)value; return USE_OK; }          // takes effect at the next use_plan
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
+#ifdef USE_HIP_EXPERIMENTS
     if (!strcmp(name, "conv_v5_min_blocks")) { conv_v5_set_min_blocks((long)value); return USE_OK; }
     if (!strcmp(name, "conv_v5_stagger")) { conv_v5_set_stagger((int)value); return USE_OK; }
+    if (!strcmp(name, "conv_v6")) { conv_v6_enable(value != 0); return USE_OK; }
+#endif
     return fail(USE_E_INVALID, "unknown option '%s'", name);
 }
 const char* use_last_error(void) { return g_err.c_str(); }
@@ -1277,7 +1280,10 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             case 0: launch_conv(a, 0); return 0;
             case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
             case 4: if (!a.wb || (XC && !a.w2b)) return -1; launch_conv_v4(a, 0); return 0;
+#ifdef USE_HIP_EXPERIMENTS
             case 5: if (!a.wb || (XC && !a.w2b) || dt == DT_F32) return -1; launch_conv_v5(a, 0); return 0;
+            case 6: if (!conv_v6_eligible(a)) return -1; launch_conv_v6(a, 0); return 0;
+#endif
             default: return -1;
         }
     };
@@ -1313,7 +1319,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
         if (hipMemcpy(out_host, outf, px * c->Cout * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(USE_E_HIP, "copy back failed");
     }
     if (stats_host && stats) {                                // per (item, channel) totals: sum over the kernel's tiles
-        const int nt = c->variant == 0 ? conv_out_tiles(a) : c->variant == 5 ? conv_v5_tiles(c->H, c->W) : c->variant == 4 ? conv_v4_tiles(c->H, c->W) : conv_v2_tiles(c->H, c->W);
+        const int nt = c->variant == 0 ? conv_out_tiles(a) : c->variant == 5 ? conv_v5_tiles(c->H, c->W) : (c->variant == 4 || c->variant == 6) ? conv_v4_tiles(c->H, c->W) : conv_v2_tiles(c->H, c->W);
         std::vector<float> hs((size_t)c->B * nt * c->Cout * 2);
         if (hipMemcpy(hs.data(), stats, hs.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(USE_E_HIP, "copy back failed");
         for (int b = 0; b < c->B; ++b)

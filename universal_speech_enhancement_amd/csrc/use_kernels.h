@@ -56,13 +56,22 @@ void launch_conv_v2(const ConvArgs& a, hipStream_t s);
 // wide-tile variant (use_conv_v4.hip): 16x32-pixel tiles, K chunks of conv_v4_chunk() channels, slab-major weights
 inline int conv_v4_chunk(int dtype) { return dtype == DT_F32 ? 16 : 32; }
 inline int conv_v4_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 31) / 32); }
-// two-workgroups-per-CU variant for 16-bit storage (use_conv_v5.hip): 8x32-pixel tiles, weights by LDS-DMA from the
-// swizzled slab-major copy
+// Measured-and-rejected schedules of the dominant convolution, built only with `make EXPERIMENTS=1` (scripts/experiments/):
+// conv_v5 = two 4-wave workgroups per CU (8x32-pixel tiles, LDS-DMA weights); conv_v6 = conv_v4's geometry with one barrier per
+// tap row, in-wave fragment prefetch and LDS-DMA weights.  Both are bit-identical to conv_v4 and no faster.
 inline int conv_v5_tiles(int H, int W) { return ((H + 7) / 8) * ((W + 31) / 32); }
+#ifdef USE_HIP_EXPERIMENTS
 bool conv_v5_eligible(const ConvArgs& a);
 void conv_v5_set_min_blocks(long n);                     // smallest per-image grid conv_v5 is used for
 void conv_v5_set_stagger(int n);                         // -1: automatic, 0: off, n: delay of the second resident workgroups
 void launch_conv_v5(const ConvArgs& a, hipStream_t s);
+bool conv_v6_eligible(const ConvArgs& a);
+void conv_v6_enable(bool on);
+void launch_conv_v6(const ConvArgs& a, hipStream_t s);
+#else
+inline bool conv_v5_eligible(const ConvArgs&) { return false; }
+inline bool conv_v6_eligible(const ConvArgs&) { return false; }
+#endif
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 128 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);

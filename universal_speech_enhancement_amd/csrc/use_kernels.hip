@@ -544,7 +544,10 @@ static void conv_launch_t(const ConvArgs& a, hipStream_t s) {
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {
+#ifdef USE_HIP_EXPERIMENTS
     if (conv_v5_eligible(a)) { launch_conv_v5(a, s); return; }
+    if (conv_v6_eligible(a)) { launch_conv_v6(a, s); return; }
+#endif
     if (conv_v4_eligible(a)) { launch_conv_v4(a, s); return; }
     if (conv_v2_eligible(a)) { launch_conv_v2(a, s); return; }
     if (pyr_conv_eligible(a)) {
