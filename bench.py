@@ -101,12 +101,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--subbatch", type=int, default=None, help="sub-batches per score evaluation (library default if unset)")
     ap.add_argument("--stagger-level", type=int, default=None)
+    ap.add_argument("--config", type=int, default=None, choices=[1, 3, 4],
+                    help="BASELINE.json configs[] preset: 1 = 8 x 4 s, N=30 PC, bf16 (the default, the headline metric); 3 = batch 16, "
+                         "N=200, corrector snr 0.5 (long-horizon latency config); 4 = 8 x 4 s per GPU, N=30 PC, fp16 storage (the "
+                         "per-GPU workload of the 32-utterance / 4-GPU config)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the timed sampler steps; run only the per-launch measurement of the dominant kernel (for "
                          "`rocprofv3 --kernel-trace --stats -- python bench.py --roofline-only`, see profiles/README.md)")
     a = ap.parse_args()
     if a.roofline_only:
         a.steps, a.warmup, a.no_cpu_baseline = 0, 0, True
+    if a.config == 3:
+        a.batch, a.N = 16, 200
+    elif a.config == 4:
+        a.precision = "fp16"
 
     from universal_speech_enhancement_amd import distributed as D
     from universal_speech_enhancement_amd.hip_engine import HipScoreEngine
@@ -172,12 +180,12 @@ def main():
     tvec = torch.full((B,), 0.5, device=dev)
     eng.profile_score(x, Y, tvec)                                   # warm
     conv_ms, conv_flops, conv_bytes, conv_launches, total_ms = eng.profile_score(x, Y, tvec)
-    peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_FP32_TFLOPS
+    peak = PEAK_FP32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS      # bf16 and fp16 MFMA share the dense peak
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
     # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), which cannot be
     # collected from inside the timed process: the committed summary of scripts/run_pmc.sh on this workload is quoted.
     traffic, traffic_src = None, None
-    if a.precision == "bf16" and (B, Tp) == (8, 640):
+    if a.precision == "bf16" and (B, Tp) == (8, 640):   # the PMC passes were collected on exactly this workload
         import glob
         pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_conv_v4.json")))
         if pm:
@@ -188,7 +196,7 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_hbm_bytes_per_launch": round(conv_bytes / max(conv_launches, 1)),
                 "kernel": "use::conv_v4_kernel<%s> (wide-tile implicit-GEMM 3x3 conv of the large maps, both ACT variants)"
-                          % ("bf16,bf16,32" if a.precision == "bf16" else "f32,f32,16"),
+                          % ({"bf16": "bf16,bf16,32", "fp16": "f16,f16,32"}.get(a.precision, "f32,f32,16")),
                 "measured": "HIP events around every launch of one eager score evaluation with the sub-batches run back to back "
                             "(one launch on the chip at a time; `rocprofv3 --stats -- python bench.py --roofline-only` agrees); in "
                             "the timed region the same launches share the chip with the other sub-batch's kernels",
@@ -197,6 +205,9 @@ def main():
                 "kernel_time_share_of_score": round(conv_ms / total_ms, 3),
                 "whole_path_tflops_per_gpu": round(tflops_path, 1), "whole_path_frac": round(tflops_path / peak, 4)}
 
+    cfg_name = ("configs[1]" if (B, a.N, ncorr, a.precision, a.seconds) == (8, 30, 1, "bf16", 4.0) else
+                "configs[3]" if (B, a.N, ncorr, a.precision, a.seconds) == (16, 200, 1, "bf16", 4.0) else
+                "configs[4] per-GPU share" if (B, a.N, ncorr, a.precision, a.seconds) == (8, 30, 1, "fp16", 4.0) else "custom")
     if rank == 0:
         res = {
             "metric": "spectrogram-frames/sec through 30-step PC sampler, 24 kHz" if (a.N, ncorr) == (30, 1)
@@ -204,7 +215,7 @@ def main():
             "value": round(value, 2), "unit": "spectrogram-frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": f"configs[1]: NCSN++ Large score net, batch={B}x{a.seconds:g} s utterances per GPU, "
+            "config": {"workload": f"{cfg_name}: NCSN++ Large score net, batch={B}x{a.seconds:g} s utterances per GPU, "
                                    f"{a.N}-step PC sampler (reverse_diffusion + {a.corrector} x1, snr 0.5, {nfe} NFE), "
                                    f"{a.precision}, hipGraph={'off' if a.no_graph else 'on'}",
                        "global_batch": world * B, "frames_per_utt": T, "padded_frames_per_utt": Tp, "n_freq": Fq,

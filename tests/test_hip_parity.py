@@ -521,3 +521,51 @@ def test_cfg2_sampler_16bit_drift_against_fp32(sd_np):
         l2_wav = float((wb - wf).pow(2).sum().sqrt() / wf.pow(2).sum().sqrt())
         print(f"[cfg2 {prec} drift] spectrogram rel-max {e_spec:.3e} rel-L2 {l2_spec:.3e}; waveform rel-max {e_wav:.3e} rel-L2 {l2_wav:.3e}")
         assert e_spec < bmax and e_wav < bmax and l2_spec < bl2 and l2_wav < bl2, (prec, e_spec, e_wav, l2_spec, l2_wav)
+
+
+def test_configs3_long_horizon_batch16_properties(sd_np):
+    """BASELINE configs[3]: N = 200 reverse steps, Langevin corrector snr 0.5, batch 16 on one GPU (400 score evaluations per
+    sampler call, sub-batches of 8 + 8, one captured hipGraph of ~2e5 kernel nodes).  Size-independent properties: the call
+    completes, the result is finite, a replay of the graph with the same seed is bit-identical, another seed differs."""
+    m = _score_model(sd_np, "bf16", corrector="langevin")
+    wav = torch.from_numpy(tnoise.synth_noisy_speech(16, 96000, seed=77)).cuda()
+    a = m.sample({"perturbed": wav}, N=200, corrector_steps=1, snr=0.5, seed=5)["enhanced"]
+    assert a.shape == (16, 96000) and torch.isfinite(a).all()
+    b = m.sample({"perturbed": wav}, N=200, corrector_steps=1, snr=0.5, seed=5)["enhanced"]
+    assert torch.equal(a, b)
+    c = m.sample({"perturbed": wav[:, :9600].contiguous()}, N=200, corrector_steps=1, snr=0.5, seed=6)["enhanced"]   # another plan: T' = 64
+    assert c.shape == (16, 9600) and torch.isfinite(c).all()
+
+
+def test_predict_cli_from_lightning_checkpoint(tmp_path, sd_np):
+    """SURVEY 8f3 / README.md:176: `predict model=SGMSE_Large ckpt_path=last.ckpt data.data_folder=... data.target_folder=...`
+    end to end from a Lightning-format checkpoint file -- `state_dict` under the reference's key layout
+    (`Score.score_net.all_modules...`), with the optimizer / EMA / bookkeeping entries such a file carries -- through the WAV
+    reader (16 kHz int16 and 24 kHz float32 inputs, i.e. with and without FFT resampling), the sampler and the WAV writer; and
+    the same run from the packed weight file (`pack_checkpoint`) gives the same audio."""
+    from scipy.io import wavfile
+    from universal_speech_enhancement_amd import pack_checkpoint as PC
+    from universal_speech_enhancement_amd import predict as P
+    sd = {"Score.score_net." + k: torch.from_numpy(v) for k, v in sd_np.items()}
+    ckpt = {"epoch": 7, "global_step": 12345, "pytorch-lightning_version": "2.2.0", "state_dict": sd,
+            "optimizer_states": [{"state": {0: {"exp_avg": torch.zeros(3)}}, "param_groups": [{"lr": 1e-4}]}],
+            "lr_schedulers": [], "loops": {}, "callbacks": {}, "hyper_parameters": {"compile": False}}
+    ckpt_path = str(tmp_path / "last.ckpt")
+    torch.save(ckpt, ckpt_path)
+    src, dst, dst2 = tmp_path / "noisy", tmp_path / "enhanced", tmp_path / "enhanced2"
+    (src / "sub").mkdir(parents=True)
+    w = tnoise.synth_noisy_speech(2, 9600, seed=3)
+    wavfile.write(str(src / "a.wav"), 24000, w[0].astype(np.float32))
+    wavfile.write(str(src / "sub" / "b.wav"), 16000, (w[1][:6400] * 32767).astype(np.int16))     # resampled to 24 kHz on load
+    common = ["model=SGMSE_Large", f"data.data_folder={src}", "model.sampler_kwargs.N=2", "model.Score.precision=fp32", "data.batch_size=2"]
+    n = P.predict(P.compose(common + [f"ckpt_path={ckpt_path}", f"data.target_folder={dst}"]))
+    assert n == 2
+    sr_a, a = wavfile.read(str(dst / "a.wav")); sr_b, b = wavfile.read(str(dst / "sub" / "b.wav"))
+    assert sr_a == sr_b == 24000 and a.shape == (9600,) and b.shape == (9600,) and np.isfinite(a).all() and np.isfinite(b).all()
+    assert float(np.abs(a).max()) > 0
+    packed = str(tmp_path / "large_fp32.usehip")
+    PC.main([f"ckpt={ckpt_path}", f"out={packed}", "precision=fp32"])
+    assert P.predict(P.compose(common + [f"ckpt_path={packed}", f"data.target_folder={dst2}"])) == 2
+    _, a2 = wavfile.read(str(dst2 / "a.wav"))
+    # device Philox noise with the default seed on both runs: same weights -> same samples
+    np.testing.assert_allclose(a2, a, rtol=0, atol=1e-6)

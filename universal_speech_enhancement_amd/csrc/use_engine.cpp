@@ -139,7 +139,7 @@ struct use_handle {
     hipEvent_t ev_fork = nullptr, ev_stagger[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr},
                ev_join[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
     int debug_B = 0;
-    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // [0]: device RNG, [1]: injected noise
+    std::vector<hipGraphExec_t> graph_exec[2];           // [0]: device RNG, [1]: injected noise; one graph per segment of steps
     hipGraphExec_t score_graph = nullptr;
     // scratch for the stand-alone use_sde_* entry points (independent of weights / plan)
     char* sde_buf = nullptr; unsigned long long* sde_rng = nullptr; float* sde_step = nullptr; float* sde_partial = nullptr;
@@ -665,14 +665,15 @@ static void predictor_coeffs(const use_config& c, int predictor, float t, int N,
 // ---------------------------------------------------------------------------------------------------------
 __global__ void set_rng_kernel(unsigned long long* st, unsigned long long seed, unsigned long long base) { st[0] = seed; st[1] = base; }
 
-static void run_sampler(use_handle* h, const float2* noise, hipStream_t s) {
+// steps [i0, i1) of the loop (i0 == 0: preceded by the prior sampling); the whole loop is run_sampler(h, noise, s, 0, N)
+static void run_sampler(use_handle* h, const float2* noise, hipStream_t s, int i0, int i1) {
     const use_sampler_config& sc = h->sc;
     const long n = (long)h->B * h->cfg.n_freq * h->T, n_per_b = (long)h->cfg.n_freq * h->T;
     const int ncorr = sc.corrector == USE_CORR_NONE ? 0 : sc.corrector_steps;
     auto nz = [&](unsigned d) { return noise ? noise + (size_t)d * n : nullptr; };
-    unsigned d = 0;
-    launch_prior(h->Y, nz(d), RngRef{h->rng_state, d}, ouve_std(h->cfg, 1.0f), h->X, n, s); d++;
-    for (int i = 0; i < sc.N; ++i) {
+    unsigned d = 1 + (unsigned)i0 * (unsigned)(ncorr + (sc.predictor == USE_PRED_NONE ? 0 : 1));   // noise draws consumed so far
+    if (i0 == 0) launch_prior(h->Y, nz(0), RngRef{h->rng_state, 0}, ouve_std(h->cfg, 1.0f), h->X, n, s);
+    for (int i = i0; i < i1; ++i) {
         const float t = h->timesteps[i];
         const float* temb = h->temb_table + (size_t)i * h->dense_rows;
         for (int k = 0; k < ncorr; ++k) {
@@ -701,7 +702,7 @@ static void run_sampler(use_handle* h, const float2* noise, hipStream_t s) {
 }
 
 static void drop_graphs(use_handle* h) {
-    for (auto& g : h->graph_exec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto& v : h->graph_exec) { for (auto g : v) if (g) (void)hipGraphExecDestroy(g); v.clear(); }
     if (h->score_graph) { (void)hipGraphExecDestroy(h->score_graph); h->score_graph = nullptr; }
 }
 
@@ -1107,7 +1108,7 @@ int use_sample(use_handle* h, const void* y, const void* noise, uint64_t seed, v
     HIPCHK(hipMemcpyAsync(h->Y, y, n * 8, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(set_rng_kernel, dim3(1), dim3(1), 0, s, h->rng_state, (unsigned long long)seed, 0ull);
     if (!h->sc.use_graph) {
-        run_sampler(h, (const float2*)noise, s);
+        run_sampler(h, (const float2*)noise, s, 0, h->sc.N);
     } else {
         const int gi = noise ? 1 : 0;
         const float2* nz = nullptr;
@@ -1117,24 +1118,34 @@ int use_sample(use_handle* h, const void* y, const void* noise, uint64_t seed, v
                 HIPCHK(hipStreamSynchronize(s));
                 if (h->noise_copy) HIPCHK(hipFree(h->noise_copy));
                 h->noise_copy = nullptr; h->noise_copy_bytes = 0;
-                if (h->graph_exec[1]) { (void)hipGraphExecDestroy(h->graph_exec[1]); h->graph_exec[1] = nullptr; }
+                for (auto g : h->graph_exec[1]) if (g) (void)hipGraphExecDestroy(g);
+                h->graph_exec[1].clear();
                 if (hipMalloc((void**)&h->noise_copy, nb) != hipSuccess) return fail(USE_E_NOMEM, "cannot allocate %.1f MB noise staging", nb / 1e6);
                 h->noise_copy_bytes = nb;
             }
             HIPCHK(hipMemcpyAsync(h->noise_copy, noise, nb, hipMemcpyDeviceToDevice, s));
             nz = h->noise_copy;
         }
-        if (!h->graph_exec[gi]) {
+        if (h->graph_exec[gi].empty()) {
+            // The loop is captured in segments of at most 64 score evaluations (~16 k kernel nodes each, the size the
+            // configs[1] graph has): one graph of the N = 200 config's 400 evaluations (~10^5 nodes) crashes the HIP runtime
+            // at instantiation.  The segments are launched back to back on the caller's stream.
             rc = ensure_cap_stream(h); if (rc) return rc;
-            hipGraph_t g = nullptr;
-            HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-            run_sampler(h, nz, h->cap_stream);
-            HIPCHK(hipStreamEndCapture(h->cap_stream, &g));
-            hipError_t e = hipGraphInstantiate(&h->graph_exec[gi], g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            if (e != hipSuccess) return fail(USE_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+            const int ncorr = h->sc.corrector == USE_CORR_NONE ? 0 : h->sc.corrector_steps;
+            const int per_seg = std::max(1, 64 / (ncorr + 1));
+            for (int i0 = 0; i0 < h->sc.N; i0 += per_seg) {
+                hipGraph_t g = nullptr;
+                hipGraphExec_t ge = nullptr;
+                HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+                run_sampler(h, nz, h->cap_stream, i0, std::min(h->sc.N, i0 + per_seg));
+                HIPCHK(hipStreamEndCapture(h->cap_stream, &g));
+                hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (e != hipSuccess) { drop_graphs(h); return fail(USE_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+                h->graph_exec[gi].push_back(ge);
+            }
         }
-        HIPCHK(hipGraphLaunch(h->graph_exec[gi], s));
+        for (auto ge : h->graph_exec[gi]) HIPCHK(hipGraphLaunch(ge, s));
     }
     HIPCHK(hipMemcpyAsync(out, h->Xmean, n * 8, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipGetLastError());
