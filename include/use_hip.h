@@ -126,6 +126,19 @@ int use_forward(use_handle* h, const void* x, const void* y, const float* t, voi
 int use_spec_fwd(const void* stft, void* Y, int B, int F, int T, int Tpad, float factor, float exponent, use_stream_t s);
 int use_spec_back(const void* X, void* stft, int B, int F, int T, int Tpad, float factor, float exponent, use_stream_t s);
 
+/* The transforms themselves on the device, fused with that glue: one kernel per direction, no intermediate
+ * buffer.  use_stft_fwd = pad_spec(spec_fwd(torch.stft(wav, n_fft, hop, window, center=True, return_complex=True)))
+ * (model_wrapper.py:116-118, 92-96, util/other.py:128-135); use_istft_back = torch.istft(spec_back(X), n_fft, hop, window,
+ * center=True, length=L) over all Tpad frames (model_wrapper.py:98-103, 120-122, 320).  wav: float32 [B][L] device, window:
+ * float32 [n_fft] device (periodic Hann in the reference's configs), Y / X: complex64 [B][1][n_fft/2+1][Tpad].  n_fft even
+ * (1022 in SGMSE_Large.yaml - not a power of two: the transforms are table-driven direct sums, 10 GFLOP per batch of 8 x 4 s),
+ * L > n_fft/2 (reflect padding), Tpad >= 1 + L / hop.  The first call per (device, n_fft) builds a twiddle table and
+ * synchronises the stream once. */
+int use_stft_fwd(const float* wav, void* Y, int B, int L, int n_fft, int hop, const float* window, int Tpad, float factor,
+                 float exponent, use_stream_t s);
+int use_istft_back(const void* X, float* wav, int B, int L, int n_fft, int hop, const float* window, int Tpad, float factor,
+                   float exponent, use_stream_t s);
+
 /* Introspection for tests / profiling */
 /* One eager score evaluation with a HIP-event pair around every launch of the dominant kernel (conv_v4_kernel, the
  * wide-tile implicit-GEMM 3x3 convolution of the large feature maps): summed kernel time, their algorithmic FLOPs and

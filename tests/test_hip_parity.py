@@ -569,3 +569,50 @@ def test_predict_cli_from_lightning_checkpoint(tmp_path, sd_np):
     _, a2 = wavfile.read(str(dst2 / "a.wav"))
     # device Philox noise with the default seed on both runs: same weights -> same samples
     np.testing.assert_allclose(a2, a, rtol=0, atol=1e-6)
+
+
+def test_device_stft_istft_match_torch():
+    """use_stft_fwd = pad_spec(spec_fwd(torch.stft(...))) and use_istft_back = torch.istft(spec_back(...)) with the
+    reference's analysis parameters (n_fft 1022, hop 160, periodic Hann, centred / reflect padding; model_wrapper.py:116-122),
+    against the CPU oracle (torch.stft / torch.istft).  Tolerances relative to the reference tensor's max magnitude:
+    spectrogram 2e-5 (direct fp32 sums of 1022 terms vs an fp32 FFT), waveform 2e-5; ragged lengths, T' > T padding frames
+    and the square-root Hann window of the GAN generator config included."""
+    from universal_speech_enhancement_amd.hip_engine import istft_decompress, stft_compress_pad
+    from universal_speech_enhancement_amd.sgmse.util.spectral import get_window
+    for L, wname in ((9600, "hann"), (6007, "hann"), (48000, "sqrthann")):
+        wav = torch.from_numpy(tnoise.synth_noisy_speech(2, L, seed=11))
+        win = get_window(wname, 1022)
+        S = torch.stft(wav, n_fft=1022, hop_length=160, window=win, center=True, return_complex=True)
+        ref = so.pad_spec(so.spec_fwd(S).unsqueeze(1))
+        Y = stft_compress_pad(wav.cuda(), win, 1022, 160, 0.15, 0.5)
+        assert Y.shape == ref.shape and Y.dtype == torch.complex64
+        assert _relmax(Y, ref) < 2e-5, (L, wname, _relmax(Y, ref))
+        assert float(Y[..., S.shape[2]:].abs().max()) == 0.0
+        # synthesis of an arbitrary (non-STFT-consistent) spectrogram, all T' frames entering as in the reference
+        X = ref * torch.from_numpy(tnoise.complex_normal(3, f"ph{L}", tuple(ref.shape))).abs().clamp(0.2, 2.0)
+        wref = torch.istft(so.spec_back(X.squeeze(1)), n_fft=1022, hop_length=160, window=win, center=True, length=L)
+        w = istft_decompress(X.cuda(), win, 1022, 160, L, 0.15, 0.5)
+        assert w.shape == wref.shape and _relmax(w, wref) < 2e-5, (L, wname, _relmax(w, wref))
+        # round trip of a consistent spectrogram gives the waveform back -- except in the last n_fft/2 samples, which the
+        # all-zero padding frames T..T'-1 overlap (they enter the envelope but carry no signal: the reference behaves the same)
+        back = istft_decompress(Y, win, 1022, 160, L, 0.15, 0.5).cpu()
+        assert _relmax(back[:, : L - 600], wav[:, : L - 600]) < 1e-4
+        assert _relmax(back, torch.istft(so.spec_back(Y.cpu().squeeze(1)), n_fft=1022, hop_length=160, window=win, center=True, length=L)) < 2e-5
+    with pytest.raises(UseHipError):
+        stft_compress_pad(torch.zeros(1, 300, device="cuda"), get_window("hann", 1022), 1022, 160, 0.15, 0.5)   # shorter than the reflect pad
+
+
+def test_sample_with_device_stft_equals_torch_stft_path(golden_dir, sd_np):
+    """ScoreModel.sample with the analysis / synthesis in libuse_hip.so vs the torch.stft / torch.istft glue: same waveform."""
+    g = dict(np.load(os.path.join(golden_dir, "sample_e2e.npz")))
+    wav = torch.from_numpy(g["wav"]).cuda()
+    Tp = (1 + wav.shape[1] // 160 + 63) // 64 * 64
+    draws = torch.from_numpy(tnoise.sampler_noise(int(g["noise_seed"]), int(g["n_draws"]), (wav.shape[0], 1, 512, Tp))).cuda()
+    outs = []
+    for dev in (True, False):
+        m = _score_model(sd_np, "fp32")
+        m.device_stft = dev
+        outs.append(m.sample({"perturbed": wav}, N=int(g["N"]), corrector_steps=int(g["corrector_steps"]), snr=float(g["snr"]),
+                             noise=draws)["enhanced"].cpu())
+    assert _relmax(outs[0], outs[1]) < 1e-4
+    assert _relmax(outs[0], torch.from_numpy(g["enhanced"])) < 2e-3

@@ -66,6 +66,8 @@ SYMBOLS = {
     "use_sample": (_i, [_vp, _vp, _vp, _u64, _vp, _vp]),
     "use_spec_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_float, C.c_float, _vp]),
     "use_spec_back": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_float, C.c_float, _vp]),
+    "use_stft_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, C.c_float, C.c_float, _vp]),
+    "use_istft_back": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, C.c_float, C.c_float, _vp]),
     "use_sde_prior": (_i, [_vp, _vp, _vp, _u64, _vp, _i64, _vp]),
     "use_sde_predictor": (_i, [_vp, _i, _f, _i, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _i64, _vp]),
     "use_sde_corrector": (_i, [_vp, _i, _f, _f, _i, _vp, _vp, _vp, _u64, _vp, _vp, _i64, _vp]),

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -1161,6 +1162,55 @@ int use_spec_fwd(const void* stft, void* Y, int B, int F, int T, int Tpad, float
 int use_spec_back(const void* X, void* stft, int B, int F, int T, int Tpad, float factor, float exponent, use_stream_t s) {
     if (!stft || !X || B < 1 || F < 1 || T < 1 || Tpad < T || factor == 0.f || exponent == 0.f) return fail(USE_E_INVALID, "bad arguments");
     launch_spec_map((const float2*)X, (float2*)stft, (long)B * F, T, Tpad, T, 1.f / factor, 1.f / exponent, 1.f, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+
+// ---- device STFT / iSTFT fused with the spectrogram glue (handle-free) -----------------------------------------
+namespace {
+std::mutex g_tw_mutex;
+std::map<std::pair<int, int>, float2*> g_tw_tables;          // (device, n_fft) -> (cos, sin)(2 pi m / n_fft); lives for the process
+int twiddles(int n_fft, hipStream_t s, const float2** out) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_tw_mutex);
+    auto it = g_tw_tables.find({dev, n_fft});
+    if (it == g_tw_tables.end()) {                            // first use on this device: build the table (synchronises once)
+        float2* tw = nullptr;
+        HIPCHK(hipMalloc((void**)&tw, (size_t)n_fft * sizeof(float2)));
+        launch_twiddle_table(tw, n_fft, s);
+        HIPCHK(hipStreamSynchronize(s));
+        it = g_tw_tables.emplace(std::make_pair(dev, n_fft), tw).first;
+    }
+    *out = it->second;
+    return USE_OK;
+}
+int check_stft_args(int B, int L, int n_fft, int hop, int Tpad) {
+    if (B < 1 || L < 1 || n_fft < 4 || (n_fft & 1) || hop < 1 || hop > n_fft) return fail(USE_E_INVALID, "bad STFT arguments (n_fft must be even, 1 <= hop <= n_fft)");
+    if (L <= n_fft / 2) return fail(USE_E_INVALID, "signal of %d samples is too short for reflect padding with n_fft=%d", L, n_fft);
+    if (Tpad < 1 + L / hop) return fail(USE_E_INVALID, "Tpad=%d is smaller than the %d frames of the signal", Tpad, 1 + L / hop);
+    if ((size_t)n_fft * 8 + (size_t)((n_fft + hop - 1) / hop) * (n_fft / 2 + 1) * 8 > 64 * 1024) return fail(USE_E_INVALID, "n_fft / hop combination exceeds the synthesis kernel's LDS");
+    return USE_OK;
+}
+}  // namespace
+
+int use_stft_fwd(const float* wav, void* Y, int B, int L, int n_fft, int hop, const float* window, int Tpad, float factor,
+                 float exponent, use_stream_t s) {
+    if (!wav || !Y || !window) return fail(USE_E_INVALID, "null argument");
+    int rc = check_stft_args(B, L, n_fft, hop, Tpad); if (rc) return rc;
+    const float2* tw = nullptr;
+    rc = twiddles(n_fft, (hipStream_t)s, &tw); if (rc) return rc;
+    launch_stft_fwd(wav, window, tw, (float2*)Y, B, L, n_fft, hop, 1 + L / hop, Tpad, factor, exponent, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+int use_istft_back(const void* X, float* wav, int B, int L, int n_fft, int hop, const float* window, int Tpad, float factor,
+                   float exponent, use_stream_t s) {
+    if (!wav || !X || !window || factor == 0.f || exponent == 0.f) return fail(USE_E_INVALID, "bad arguments");
+    int rc = check_stft_args(B, L, n_fft, hop, Tpad); if (rc) return rc;
+    const float2* tw = nullptr;
+    rc = twiddles(n_fft, (hipStream_t)s, &tw); if (rc) return rc;
+    launch_istft_back((const float2*)X, window, tw, wav, B, L, n_fft, hop, Tpad, factor, exponent, (hipStream_t)s);
     HIPCHK(hipGetLastError());
     return USE_OK;
 }

@@ -96,6 +96,14 @@ void launch_fir_down2(const void* src, int dtype, const float* coef, int act, vo
 void launch_spec_map(const float2* in, float2* out, long rows, int Tin, int Tin_stride, int Tout, float pre, float power,
                      float post, hipStream_t s);
 
+// Device STFT / iSTFT fused with the compression glue (n_fft N even, F = N/2 + 1 bins, centred frames, reflect padding).
+// tw = table of (cos, sin)(2 pi m / N), m < N (launch_twiddle_table); win = analysis / synthesis window [N] (device).
+void launch_twiddle_table(float2* tw, int N, hipStream_t s);
+void launch_stft_fwd(const float* wav, const float* win, const float2* tw, float2* Y, int B, int L, int N, int hop, int T,
+                     int Tpad, float factor, float expo, hipStream_t s);
+void launch_istft_back(const float2* X, const float* win, const float2* tw, float* wav, int B, int L, int N, int hop, int Tpad,
+                       float factor, float expo, hipStream_t s);
+
 // x4[b,f,t,:] = 2*(x.re, x.im, y.re, y.im) - 1   (fp32), x/y complex64 [B,F,T]
 void launch_pack_input(const float2* x, const float2* y, float* x4, long npix, hipStream_t s);
 

@@ -929,6 +929,142 @@ void launch_spec_map(const float2* in, float2* out, long rows, int Tin, int Tin_
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Device STFT / iSTFT fused with the spectrogram glue (reference model_wrapper.py:116-122 torch.stft / torch.istft
+// with n_fft = 1022, hop 160, periodic Hann, center=True; 92-103 compression; util/other.py:128-135 padding).
+// n_fft = 1022 = 2 * 7 * 73 is no radix-2 length (rocFFT runs it as Bluestein); at 0.6 k frames per utterance the transforms
+// are 10 GFLOP per batch as plain DFTs, so each direction is ONE kernel of table-driven direct sums: exact twiddles
+// cos/sin(2 pi m / N) from a table computed in double precision, indexed by (k n) mod N with an incremental index, fp32
+// accumulation - and windowing, reflect padding, compression, frame padding / overlap-add, envelope normalisation and the
+// [B][F][T'] layout all happen in the same pass, with no intermediate buffer.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void twiddle_table_kernel(float2* tw, int N) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < N) {
+        double sn, cs;
+        sincospi(2.0 * (double)m / (double)N, &sn, &cs);
+        tw[m] = make_float2((float)cs, (float)sn);
+    }
+}
+void launch_twiddle_table(float2* tw, int N, hipStream_t s) {
+    hipLaunchKernelGGL(twiddle_table_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tw, N);
+}
+
+// Y[b][0][k][t] = compress(sum_n w[n] y_b[reflect(t hop + n - N/2)] e^{-2 pi i k n / N}), zero for T <= t < Tpad.
+// One workgroup per (frame, item): the windowed frame and the twiddle table sit in LDS, every thread owns bins k, k + 256.
+__global__ __launch_bounds__(256) void stft_fwd_kernel(const float* __restrict__ wav, const float* __restrict__ win,
+                                                       const float2* __restrict__ tw, float2* __restrict__ Y, int L, int N,
+                                                       int hop, int T, int Tpad, int F, float factor, float expo) {
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    float* xs = reinterpret_cast<float*>(fsm);                              // [N] windowed frame
+    float2* tws = reinterpret_cast<float2*>(fsm + ((N * 4 + 15) & ~15));    // [N] twiddles
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (t >= T) {                                             // frame padding (pad_spec)
+        for (int k = tid; k < F; k += 256) Y[((size_t)b * F + k) * Tpad + t] = make_float2(0.f, 0.f);
+        return;
+    }
+    for (int n = tid; n < N; n += 256) {
+        int q = t * hop + n - N / 2;                          // center=True: reflect padding of N/2 samples on both sides
+        if (q < 0) q = -q;
+        if (q >= L) q = 2 * (L - 1) - q;
+        xs[n] = wav[(size_t)b * L + q] * win[n];
+        tws[n] = tw[n];
+    }
+    __syncthreads();
+    for (int k = tid; k < F; k += 256) {
+        float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f;     // two partial sums: shorter dependency chains, smaller error
+        int idx = 0;
+        int n = 0;
+        for (; n + 1 < N; n += 2) {
+            const float2 c0 = tws[idx]; idx += k; if (idx >= N) idx -= N;
+            const float2 c1 = tws[idx]; idx += k; if (idx >= N) idx -= N;
+            const float x0 = xs[n], x1 = xs[n + 1];
+            re0 = fmaf(x0, c0.x, re0); im0 = fmaf(-x0, c0.y, im0);
+            re1 = fmaf(x1, c1.x, re1); im1 = fmaf(-x1, c1.y, im1);
+        }
+        if (n < N) { const float2 c0 = tws[idx]; re0 = fmaf(xs[n], c0.x, re0); im0 = fmaf(-xs[n], c0.y, im0); }
+        const float re = re0 + re1, im = im0 + im1;
+        const float a = hypotf(re, im);
+        const float sc = a > 0.f ? powf(a, expo - 1.f) * factor : 0.f;      // |S|^e e^{j arg S} * factor = S |S|^(e-1) factor
+        Y[((size_t)b * F + k) * Tpad + t] = make_float2(re * sc, im * sc);
+    }
+}
+void launch_stft_fwd(const float* wav, const float* win, const float2* tw, float2* Y, int B, int L, int N, int hop, int T,
+                     int Tpad, float factor, float expo, hipStream_t s) {
+    const size_t sh = ((size_t)N * 4 + 15 & ~(size_t)15) + (size_t)N * 8;
+    hipLaunchKernelGGL(stft_fwd_kernel, dim3(Tpad, B), dim3(256), sh, s, wav, win, tw, Y, L, N, hop, T, Tpad, N / 2 + 1, factor, expo);
+}
+
+// y_b[m] = sum_t w[n] x_t[n] / sum_t w[n]^2, n = m + N/2 - t hop in [0, N), over the T' frames, with
+// x_t[n] = (1/N) (Re S_0 + (-1)^n Re S_{F-1} + 2 sum_{k=1}^{F-2} (Re S_k cos(2 pi k n / N) - Im S_k sin(2 pi k n / N)))   (irfft),
+// S = decompress(X).  One workgroup per (hop-sized block of output samples, item): every output sample of the block meets the
+// same <= ceil(N / hop) frames, whose decompressed spectra are staged in LDS once.
+__global__ __launch_bounds__(256) void istft_back_kernel(const float2* __restrict__ X, const float* __restrict__ win,
+                                                         const float2* __restrict__ tw, float* __restrict__ wav, int L, int N,
+                                                         int hop, int Tpad, int F, int nfr, float inv_factor, float inv_expo) {
+    extern __shared__ __attribute__((aligned(16))) char ism[];
+    float2* tws = reinterpret_cast<float2*>(ism);                           // [N]
+    float2* sp = reinterpret_cast<float2*>(ism + (size_t)N * 8);            // [nfr][F] decompressed spectra of the frames in reach
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int t_hi = h;                                       // frames t_hi - nfr + 1 .. t_hi can reach samples [h hop, (h + 1) hop)
+    for (int n = tid; n < N; n += 256) tws[n] = tw[n];
+    for (int i = tid; i < nfr * F; i += 256) {
+        const int j = i / F, k = i - j * F;
+        const int t = t_hi - j;
+        float2 o = make_float2(0.f, 0.f);
+        if (t >= 0 && t < Tpad) {
+            const float2 z = X[((size_t)b * F + k) * Tpad + t];
+            const float a = hypotf(z.x, z.y) * inv_factor;
+            const float sc = a > 0.f ? powf(a, inv_expo - 1.f) * inv_factor : 0.f;
+            o = make_float2(z.x * sc, z.y * sc);
+        }
+        sp[i] = o;
+    }
+    __syncthreads();
+    const float invN = 1.0f / (float)N;
+    for (int r = tid; r < hop; r += 256) {
+        const int g = h * hop + r;                            // sample index in the centre-padded signal
+        const int m = g - N / 2;                              // output sample
+        if (m < 0 || m >= L) continue;
+        float acc = 0.f, env = 0.f;
+        for (int j = 0; j < nfr; ++j) {
+            const int t = t_hi - j;
+            const int n = g - t * hop;                        // = j hop + r
+            if (t < 0 || t >= Tpad || n >= N) continue;
+            const float2* S = sp + j * F;
+            float s0 = 0.f, s1 = 0.f;
+            int idx = n; if (idx >= N) idx -= N;              // (k n) mod N for k = 1
+            int k = 1;
+            for (; k + 1 < F - 1; k += 2) {
+                const float2 c0 = tws[idx]; idx += n; if (idx >= N) idx -= N;
+                const float2 c1 = tws[idx]; idx += n; if (idx >= N) idx -= N;
+                const float2 a0 = S[k], a1 = S[k + 1];
+                s0 = fmaf(a0.x, c0.x, s0); s0 = fmaf(-a0.y, c0.y, s0);
+                s1 = fmaf(a1.x, c1.x, s1); s1 = fmaf(-a1.y, c1.y, s1);
+            }
+            for (; k < F - 1; ++k) {
+                const float2 c0 = tws[idx]; idx += n; if (idx >= N) idx -= N;
+                const float2 a0 = S[k];
+                s0 = fmaf(a0.x, c0.x, s0); s0 = fmaf(-a0.y, c0.y, s0);
+            }
+            const float x = (S[0].x + ((n & 1) ? -S[F - 1].x : S[F - 1].x) + 2.f * (s0 + s1)) * invN;
+            const float w = win[n];
+            acc = fmaf(w, x, acc); env = fmaf(w, w, env);
+        }
+        wav[(size_t)b * L + m] = env > 1e-11f ? acc / env : 0.f;
+    }
+}
+void launch_istft_back(const float2* X, const float* win, const float2* tw, float* wav, int B, int L, int N, int hop, int Tpad,
+                       float factor, float expo, hipStream_t s) {
+    const int F = N / 2 + 1, nfr = (N + hop - 1) / hop;
+    const int nblocks = (L + N / 2 + hop - 1) / hop;          // blocks of centre-padded samples that reach an output sample
+    const size_t sh = (size_t)N * 8 + (size_t)nfr * F * 8;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(istft_back_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(istft_back_kernel, dim3(nblocks, B), dim3(256), sh, s, X, win, tw, wav, L, N, hop, Tpad, F, nfr, 1.f / factor,
+                       1.f / expo);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Input packing
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_input_kernel(const float2* __restrict__ x, const float2* __restrict__ y,

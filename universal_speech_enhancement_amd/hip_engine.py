@@ -61,6 +61,34 @@ def spec_decompress_crop(X: torch.Tensor, T: int, factor: float, exponent: float
     return S
 
 
+def stft_compress_pad(wav: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, factor: float, exponent: float,
+                      multiple: int = 64) -> torch.Tensor:
+    """``pad_spec(spec_fwd(stft(wav)).unsqueeze(1))`` in one kernel (``use_stft_fwd``): float32 CUDA [B, L] -> complex64 [B,1,F,T']."""
+    if not wav.is_cuda or wav.dtype != torch.float32 or wav.dim() != 2:
+        raise UseHipError("stft_compress_pad needs a float32 CUDA tensor [B, L]")
+    wav, window = wav.contiguous(), window.to(device=wav.device, dtype=torch.float32).contiguous()
+    B, L = wav.shape
+    T = 1 + L // hop
+    Tp = (T + multiple - 1) // multiple * multiple
+    Y = torch.empty((B, 1, n_fft // 2 + 1, Tp), dtype=torch.complex64, device=wav.device)
+    check(_lib.lib().use_stft_fwd(wav.data_ptr(), Y.data_ptr(), B, L, int(n_fft), int(hop), window.data_ptr(), Tp, float(factor),
+                                  float(exponent), _stream_ptr(wav.device)), "use_stft_fwd")
+    return Y
+
+
+def istft_decompress(X: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, length: int, factor: float,
+                     exponent: float) -> torch.Tensor:
+    """``istft(spec_back(X.squeeze(1)), length)`` in one kernel (``use_istft_back``): complex64 CUDA [B,1,F,T'] -> float32 [B, length]."""
+    if not X.is_cuda or X.dtype != torch.complex64 or X.dim() != 4 or X.shape[1] != 1 or X.shape[2] != n_fft // 2 + 1:
+        raise UseHipError("istft_decompress needs a complex64 CUDA tensor [B, 1, n_fft/2+1, T']")
+    X, window = X.contiguous(), window.to(device=X.device, dtype=torch.float32).contiguous()
+    B, _, _, Tp = X.shape
+    wav = torch.empty((B, int(length)), dtype=torch.float32, device=X.device)
+    check(_lib.lib().use_istft_back(X.data_ptr(), wav.data_ptr(), B, int(length), int(n_fft), int(hop), window.data_ptr(), Tp,
+                                    float(factor), float(exponent), _stream_ptr(X.device)), "use_istft_back")
+    return wav
+
+
 class HipScoreEngine:
     """One handle per (process, device).  Not re-entrant."""
 

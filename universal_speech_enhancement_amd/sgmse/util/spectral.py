@@ -54,8 +54,16 @@ class SpectralGlue:
     def spec_back(self, spec):
         return self._power_law(spec / self.spec_factor, 1 / self.spec_abs_exponent)
 
+    device_stft = True     # CUDA tensors: analysis / synthesis in libuse_hip.so (use_stft_fwd / use_istft_back); False: torch.stft / istft
+
+    def _device_stft_ok(self, length):
+        return self.device_stft and self.n_fft % 2 == 0 and length > self.n_fft // 2 and self.hop_length <= self.n_fft
+
     def _spectrogram(self, y):
         """waveform [B, L] -> compressed spectrogram [B, 1, F, T'] with T' padded to a multiple of 64 frames."""
+        if y.is_cuda and y.dtype == torch.float32 and self._device_stft_ok(y.shape[1]):
+            from ...hip_engine import stft_compress_pad
+            return stft_compress_pad(y, self._get_window(y), self.n_fft, self.hop_length, self.spec_factor, self.spec_abs_exponent)
         S = self.stft(y)
         if S.is_cuda:
             from ...hip_engine import spec_compress_pad
@@ -65,6 +73,9 @@ class SpectralGlue:
     def _waveform(self, X, length):
         """[B, 1, F, T'] -> waveform [B, length].  All T' frames enter the iSTFT, as in the reference: the frames of the
         padding region overlap the last n_fft/2 samples of the signal."""
+        if X.is_cuda and length is not None and self._device_stft_ok(length) and X.shape[3] >= 1 + length // self.hop_length:
+            from ...hip_engine import istft_decompress
+            return istft_decompress(X, self._get_window(X), self.n_fft, self.hop_length, length, self.spec_factor, self.spec_abs_exponent)
         if X.is_cuda:
             from ...hip_engine import spec_decompress_crop
             return self.istft(spec_decompress_crop(X, X.shape[3], self.spec_factor, self.spec_abs_exponent), length)
