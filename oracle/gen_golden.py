@@ -18,6 +18,7 @@ Fixtures
                     euler_maruyama x {none, langevin}                                (G3)
   sample_e2e.npz    ScoreModel.sample, 0.4 s utterance, N=3, langevin x1             (G4)
   sample_cfg1.npz   BASELINE cfg1: 2 s utterance, N=5, reverse_diffusion+langevin    (G5, ~70 s)
+  forward_12m/6m.npz NCSNpp12M / NCSNpp6M (nf = 96) forward [2,2,512,64]                  
   refine.npz        LSGAN refine generator: NCSNpp(discriminative=True).forward [2,1,512,64] and
                     NCSNPP_Wrapper inference on 2 x 0.4 s                           
 """
@@ -215,6 +216,22 @@ def gen_sample_cfg1(model=None):
     _sample_case(m, crc, "sample_cfg1.npz", 1, 48000, 5, 1, seed=1234)
 
 
+def gen_forward_small():
+    """NCSNpp12M / NCSNpp6M (nf = 96; reference ncsnpp.py:527-559) forward at [2,2,512,64], t = (0.8, 0.1)."""
+    from src.models.components.sgmse.backbones.ncsnpp import NCSNpp12M, NCSNpp6M
+    x = torch.from_numpy(tnoise.complex_normal(17, "small_x", (2, 2, 512, 64))) * 0.5
+    t = torch.tensor([0.8, 0.1])
+    for name, cls, arch in (("12m", NCSNpp12M, tw.SMALL12M), ("6m", NCSNpp6M, tw.SMALL6M)):
+        net = cls(input_channels=4).eval()
+        sd = tw.make_state_dict(4242, **arch)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        with torch.no_grad():
+            out = net(x, t)
+        # (the input is regenerated from its seed by the tests: tnoise.complex_normal(17, "small_x", (2, 2, 512, 64)) * 0.5)
+        np.savez(os.path.join(OUT, f"forward_{name}.npz"), x_seed=17, t=t.numpy(), out=out.numpy(), weights_seed=4242,
+                 weights_crc=tw.weights_checksum(sd))
+
+
 def gen_refine(model=None):
     """LSGAN refine stage: NCSNPP_Wrapper(n_fft=1022, hop=160, num_frames=480) = NCSNpp(discriminative=True)
     between STFT glue (GAN/generator/ncsnpp/model_wrapper.py:19-121, configs/model/LSGAN.yaml:46-53)."""
@@ -238,7 +255,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     small = {"fir": gen_fir, "resblocks": gen_resblocks, "attn": gen_attn, "samplers": gen_samplers, "samplers_em": gen_samplers_em,
-             "refine": gen_refine}
+             "refine": gen_refine, "forward_small": gen_forward_small}
     big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1}
     todo = [a.only] if a.only else list(small) + list(big)
     model = build_reference_large() if any(n in big for n in todo) else None

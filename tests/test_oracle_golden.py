@@ -127,3 +127,17 @@ def test_refine_generator_matches_reference(golden_dir):
     assert np.abs(out.numpy() - g["out"]).max() / np.abs(g["out"]).max() < 2e-5
     assert np.abs(fake.numpy() - g["fake"]).max() / np.abs(g["fake"]).max() < 1e-4
 
+
+
+@pytest.mark.parametrize("name,arch", [("12m", tw.SMALL12M), ("6m", tw.SMALL6M)])
+def test_small_variants_match_reference(golden_dir, name, arch):
+    """NCSNpp12M / NCSNpp6M (nf = 96, reference ncsnpp.py:527-559): oracle forward vs outputs of the reference's own modules."""
+    g = _load(golden_dir, f"forward_{name}.npz")
+    sd_np = tw.make_state_dict(int(g["weights_seed"]), **arch)
+    assert str(g["weights_crc"]) == tw.weights_checksum(sd_np)
+    x = torch.from_numpy(tnoise.complex_normal(int(g["x_seed"]), "small_x", (2, 2, 512, 64))) * 0.5
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    with torch.no_grad():
+        out = no.ncsnpp_forward(no.to_torch(sd_np), x, torch.from_numpy(g["t"]), ch_mult=arch["ch_mult"], num_res_blocks=arch["num_res_blocks"])
+    err = np.abs(out.numpy() - g["out"]).max() / np.abs(g["out"]).max()
+    assert err < 2e-5, err

@@ -507,8 +507,9 @@ static void v2_launch_t(const ConvArgs& a, hipStream_t s) {
 bool conv_v2_eligible(const ConvArgs& a) {
     const int Ctot = a.C0 + a.C1, XC = a.XC0 + a.XC1;
     const int ck = a.in_dtype == DT_F32 ? 32 : 64;
-    return a.ntaps == 9 && a.Cout > 32 && a.in_dtype == a.out_dtype && Ctot % ck == 0 && XC % ck == 0 && a.H >= V2_T &&
-           a.W >= V2_T;
+    return a.ntaps == 9 && a.Cout > 32 && a.in_dtype == a.out_dtype && Ctot % ck == 0 && XC % ck == 0 &&
+           (a.C1 == 0 || a.C0 % ck == 0) && (a.XC1 == 0 || a.XC0 % ck == 0) &&      // a chunk never straddles the two sources
+           a.H >= V2_T && a.W >= V2_T;
 }
 
 void launch_conv_v2(const ConvArgs& a0, hipStream_t s) {

@@ -457,7 +457,7 @@ bool conv_v4_eligible(const ConvArgs& a) {
     // (per image, so that the kernel choice - and with it the summation order - does not depend on the batch size)
     const long blocks = (long)conv_v4_tiles(a.H, a.W) * ((a.Cout + V4_BN - 1) / V4_BN);
     return !off && a.wb != nullptr && (XC == 0 || a.w2b != nullptr) && a.ntaps == 9 && a.Cout > 32 && a.in_dtype == a.out_dtype &&
-           Ctot % ck == 0 && XC % ck == 0 && a.cout_pad % V4_BN == 0 && a.H % V4_TH == 0 && a.W % V4_TW == 0 && blocks >= g_v4_min_blocks;
+           Ctot % ck == 0 && XC % ck == 0 && (a.C1 == 0 || a.C0 % ck == 0) && (a.XC1 == 0 || a.XC0 % ck == 0) && a.cout_pad % V4_BN == 0 && a.H % V4_TH == 0 && a.W % V4_TW == 0 && blocks >= g_v4_min_blocks;
 }
 
 void launch_conv_v4(const ConvArgs& a0, hipStream_t s) {

@@ -747,8 +747,10 @@ const char* use_version(void) { return "use_hip 0.1 (gfx950)"; }
 
 int use_create(const use_config* cfg, int device, use_handle** out) {
     if (!cfg || !out) return fail(USE_E_INVALID, "null argument");
-    if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->nf % 64 != 0 || cfg->num_res_blocks < 1)
-        return fail(USE_E_INVALID, "unsupported architecture (nf must be a multiple of 64, 1..8 levels)");
+    if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->nf % 32 != 0 || cfg->nf < 32 || cfg->num_res_blocks < 1)
+        return fail(USE_E_INVALID, "unsupported architecture (nf must be a multiple of 32, 1..8 levels)");
+    for (int i = 0; i < cfg->n_levels; ++i)
+        if (cfg->ch_mult[i] < 1 || cfg->nf * cfg->ch_mult[i] > 512) return fail(USE_E_INVALID, "unsupported architecture (1 <= nf * ch_mult <= 512)");
     if (cfg->n_freq % (1 << (cfg->n_levels - 1)) != 0)
         return fail(USE_E_INVALID, "n_freq=%d is not divisible by 2^(levels-1)", cfg->n_freq);
     if (cfg->precision != USE_PREC_FP32 && cfg->precision != USE_PREC_BF16 && cfg->precision != USE_PREC_FP16) return fail(USE_E_INVALID, "bad precision");

@@ -570,13 +570,24 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     }
     const int Ctot = a.C0 + a.C1;
     const bool small_n = a.Cout <= 32;
+    // 16-bit activations: 64-channel chunks, or 32 (nf = 96 networks); a chunk never straddles the two concatenated sources
+    const bool ck64 = Ctot % 64 == 0 && (a.XC0 + a.XC1) % 64 == 0 && (a.C1 == 0 || a.C0 % 64 == 0) && (a.XC1 == 0 || a.XC0 % 64 == 0);
     if (a.in_dtype == DT_BF16) {
-        // 16-bit activations: 64-channel chunks
-        if (a.out_dtype == DT_BF16) { small_n ? conv_launch_t<__bf16, __bf16, 64, 32, 4, 1>(a, s) : conv_launch_t<__bf16, __bf16, 64, 128, 2, 2>(a, s); }
-        else                        { small_n ? conv_launch_t<__bf16, float, 64, 32, 4, 1>(a, s) : conv_launch_t<__bf16, float, 64, 128, 2, 2>(a, s); }
+        if (ck64) {
+            if (a.out_dtype == DT_BF16) { small_n ? conv_launch_t<__bf16, __bf16, 64, 32, 4, 1>(a, s) : conv_launch_t<__bf16, __bf16, 64, 128, 2, 2>(a, s); }
+            else                        { small_n ? conv_launch_t<__bf16, float, 64, 32, 4, 1>(a, s) : conv_launch_t<__bf16, float, 64, 128, 2, 2>(a, s); }
+        } else {
+            if (a.out_dtype == DT_BF16) { small_n ? conv_launch_t<__bf16, __bf16, 32, 32, 4, 1>(a, s) : conv_launch_t<__bf16, __bf16, 32, 128, 2, 2>(a, s); }
+            else                        { small_n ? conv_launch_t<__bf16, float, 32, 32, 4, 1>(a, s) : conv_launch_t<__bf16, float, 32, 128, 2, 2>(a, s); }
+        }
     } else if (a.in_dtype == DT_F16) {
-        if (a.out_dtype == DT_F16) { small_n ? conv_launch_t<_Float16, _Float16, 64, 32, 4, 1>(a, s) : conv_launch_t<_Float16, _Float16, 64, 128, 2, 2>(a, s); }
-        else                       { small_n ? conv_launch_t<_Float16, float, 64, 32, 4, 1>(a, s) : conv_launch_t<_Float16, float, 64, 128, 2, 2>(a, s); }
+        if (ck64) {
+            if (a.out_dtype == DT_F16) { small_n ? conv_launch_t<_Float16, _Float16, 64, 32, 4, 1>(a, s) : conv_launch_t<_Float16, _Float16, 64, 128, 2, 2>(a, s); }
+            else                       { small_n ? conv_launch_t<_Float16, float, 64, 32, 4, 1>(a, s) : conv_launch_t<_Float16, float, 64, 128, 2, 2>(a, s); }
+        } else {
+            if (a.out_dtype == DT_F16) { small_n ? conv_launch_t<_Float16, _Float16, 32, 32, 4, 1>(a, s) : conv_launch_t<_Float16, _Float16, 32, 128, 2, 2>(a, s); }
+            else                       { small_n ? conv_launch_t<_Float16, float, 32, 32, 4, 1>(a, s) : conv_launch_t<_Float16, float, 32, 128, 2, 2>(a, s); }
+        }
     } else {
         if (Ctot % 32 == 0) {
             if (a.out_dtype == DT_BF16)     { small_n ? conv_launch_t<float, __bf16, 32, 32, 4, 1>(a, s) : conv_launch_t<float, __bf16, 32, 128, 2, 2>(a, s); }

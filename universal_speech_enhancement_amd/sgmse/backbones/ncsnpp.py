@@ -163,6 +163,22 @@ class NCSNppLarge(NCSNpp):
         super().__init__(nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, **kwargs)
 
 
+@BackboneRegistry.register("ncsnpp12M")
+class NCSNpp12M(NCSNpp):
+    """nf=96, ch_mult=(1,2,2,1), one res-block per level, ~12 M parameters (reference ncsnpp.py:527-541)."""
+
+    def __init__(self, **kwargs):
+        super().__init__(nf=96, ch_mult=(1, 2, 2, 1), num_res_blocks=1, **kwargs)
+
+
+@BackboneRegistry.register("ncsnpp6M")
+class NCSNpp6M(NCSNpp):
+    """nf=96, ch_mult=(1,1,1,1), one res-block per level, ~6 M parameters (reference ncsnpp.py:545-559)."""
+
+    def __init__(self, **kwargs):
+        super().__init__(nf=96, ch_mult=(1, 1, 1, 1), num_res_blocks=1, **kwargs)
+
+
 # explicit names for configs that want to state the implementation
 BackboneRegistry.register("ncsnpp_hip")(NCSNpp)
 BackboneRegistry.register("ncsnpplarge_hip")(NCSNppLarge)
