@@ -106,6 +106,10 @@ int use_set_sampler(use_handle* h, const use_sampler_config* sc);
 int use_num_noise_draws(use_handle* h);
 int use_get_timesteps(use_handle* h, float* out, int n);
 int use_sample(use_handle* h, const void* y, const void* noise, uint64_t seed, void* out, use_stream_t stream);
+/* The same loop with the score conditioning separated from the SDE's y: the network sees cat[x, cond] while the drift, the
+ * prior mean and the result refer to y -- ScoreModel.sample with condition="denoised" (conditioning = the GAN-denoised
+ * spectrogram) and sde_input "noisy" or "denoised" (model_wrapper.py:283-301).  cond == NULL is use_sample. */
+int use_sample_cond(use_handle* h, const void* y, const void* cond, const void* noise, uint64_t seed, void* out, use_stream_t stream);
 
 /* Element-wise SDE pieces for callers that drive the loop themselves through the reference's
  * Predictor / Corrector registries (uniform t over the batch). n = number of complex elements. */

@@ -18,6 +18,7 @@ Fixtures
                     euler_maruyama x {none, langevin}                                (G3)
   sample_e2e.npz    ScoreModel.sample, 0.4 s utterance, N=3, langevin x1             (G4)
   sample_cfg1.npz   BASELINE cfg1: 2 s utterance, N=5, reverse_diffusion+langevin    (G5, ~70 s)
+  sample_denoised.npz ScoreModel.sample with condition="denoised", sde_input in {noisy, denoised}  (model_wrapper.py:283-328)
   forward_12m/6m.npz NCSNpp12M / NCSNpp6M (nf = 96) forward [2,2,512,64]                  
   refine.npz        LSGAN refine generator: NCSNpp(discriminative=True).forward [2,1,512,64] and
                     NCSNPP_Wrapper inference on 2 x 0.4 s                           
@@ -232,6 +233,33 @@ def gen_forward_small():
                  weights_crc=tw.weights_checksum(sd))
 
 
+def gen_sample_denoised(model=None):
+    """ScoreModel.sample with condition="denoised" (the network is conditioned on the GAN-denoised spectrogram,
+    model_wrapper.py:285-286) for both choices of sde_input (:293-300, 320-328): 0.4 s utterance, N=3, langevin x1."""
+    _, crc = model or build_reference_large()
+    wav = torch.from_numpy(tnoise.synth_noisy_speech(1, 9600, seed=77))
+    fake = torch.from_numpy(tnoise.synth_noisy_speech(1, 9600, seed=78)) * 0.7 + 0.3 * wav      # stand-in for the GAN's output
+    draws = tnoise.sampler_noise(4321, 1 + 3 * 2, (1, 1, 512, 64))
+    out = {}
+    for sde_input in ("noisy", "denoised"):
+        torch.manual_seed(0)
+        m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition="denoised", n_fft=1022, hop_length=160,
+                       num_frames=512, window="hann", sde_input=sde_input, predictor="reverse_diffusion", corrector="langevin").eval()
+        sd = tw.make_state_dict(1234, **tw.LARGE)
+        m.score_net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        orig = torch.randn_like
+        torch.randn_like = _Replay(list(draws))
+        try:
+            with torch.no_grad():
+                b = m.sample({"perturbed": wav.clone(), "fake": fake.clone()}, N=3, corrector_steps=1, snr=0.5)
+        finally:
+            torch.randn_like = orig
+        out[sde_input] = b["enhanced" if sde_input == "noisy" else "fake_sde_enhanced"].numpy()
+    np.savez(os.path.join(OUT, "sample_denoised.npz"), wav=wav.numpy(), fake=fake.numpy(), out_sde_noisy=out["noisy"],
+             out_sde_denoised=out["denoised"], N=3, corrector_steps=1, snr=0.5, noise_seed=4321, n_draws=7, weights_seed=1234,
+             weights_crc=crc)
+
+
 def gen_refine(model=None):
     """LSGAN refine stage: NCSNPP_Wrapper(n_fft=1022, hop=160, num_frames=480) = NCSNpp(discriminative=True)
     between STFT glue (GAN/generator/ncsnpp/model_wrapper.py:19-121, configs/model/LSGAN.yaml:46-53)."""
@@ -256,7 +284,8 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     small = {"fir": gen_fir, "resblocks": gen_resblocks, "attn": gen_attn, "samplers": gen_samplers, "samplers_em": gen_samplers_em,
              "refine": gen_refine, "forward_small": gen_forward_small}
-    big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1}
+    big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1,
+           "sample_denoised": gen_sample_denoised}
     todo = [a.only] if a.only else list(small) + list(big)
     model = build_reference_large() if any(n in big for n in todo) else None
     for n in todo:

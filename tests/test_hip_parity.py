@@ -632,3 +632,32 @@ def test_nf96_variants_match_reference(golden_dir, name, arch, backbone, prec, t
     out = net(x.cuda(), torch.from_numpy(g["t"]).cuda())
     err = _relmax(out, g["out"])
     assert err < tol, (name, prec, err)
+
+
+@pytest.mark.parametrize("sde_input", ["noisy", "denoised"])
+def test_condition_denoised_matches_reference(golden_dir, sd_np, sde_input):
+    """ScoreModel.sample with condition="denoised" (score conditioning = the GAN-denoised spectrogram, model_wrapper.py:285-286)
+    and both choices of sde_input (:293-300; the result key follows :320-328), fused path (use_sample_cond), against outputs of
+    the reference; and the seam path (Python-driven loop) agrees with the fused one."""
+    from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel
+    g = dict(np.load(os.path.join(golden_dir, "sample_denoised.npz")))
+    m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition="denoised", n_fft=1022, hop_length=160, num_frames=512,
+                   window="hann", sde_input=sde_input, predictor="reverse_diffusion", corrector="langevin", precision="fp32")
+    m.score_net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    draws = torch.from_numpy(tnoise.sampler_noise(int(g["noise_seed"]), int(g["n_draws"]), (1, 1, 512, 64))).cuda()
+    batch = {"perturbed": torch.from_numpy(g["wav"]).cuda(), "fake": torch.from_numpy(g["fake"]).cuda()}
+    out = m.sample(dict(batch), N=int(g["N"]), corrector_steps=1, snr=0.5, noise=draws)
+    key = "enhanced" if sde_input == "noisy" else "fake_sde_enhanced"
+    assert key in out and ("fake_sde_enhanced" if sde_input == "noisy" else "enhanced") not in out
+    assert _relmax(out[key], g["out_sde_" + sde_input]) < 2e-3
+    # seam path: same sampler driven from Python through the registries (score_fn = ScoreModel.forward -> use_score)
+    from universal_speech_enhancement_amd.sgmse import sampling
+    Y, Yd = m._spectrogram(batch["perturbed"]), m._spectrogram(batch["fake"])
+    ysde = Y if sde_input == "noisy" else Yd
+    sde = m.sde.copy(); sde.N = int(g["N"])
+    seam, _ = sampling.get_pc_sampler("reverse_diffusion", "langevin", sde=sde, y=ysde, eps=m.t_eps, snr=0.5, corrector_steps=1,
+                                      score_fn=lambda x, t, score_conditioning=None, sde_input=None: m(x, t, score_conditioning, sde_input),
+                                      conditioning=[Yd], noise=draws)()
+    assert _relmax(m._waveform(seam, 9600), out[key]) < 1e-4
+    with pytest.raises(NotImplementedError):
+        m.sample({"perturbed": batch["perturbed"]}, N=1)                    # condition="denoised" without batch["fake"]

@@ -64,6 +64,7 @@ SYMBOLS = {
     "use_num_noise_draws": (_i, [_vp]),
     "use_get_timesteps": (_i, [_vp, C.POINTER(_f), _i]),
     "use_sample": (_i, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    "use_sample_cond": (_i, [_vp, _vp, _vp, _vp, _u64, _vp, _vp]),
     "use_spec_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_float, C.c_float, _vp]),
     "use_spec_back": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_float, C.c_float, _vp]),
     "use_stft_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, C.c_float, C.c_float, _vp]),

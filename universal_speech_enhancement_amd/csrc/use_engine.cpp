@@ -122,6 +122,8 @@ struct use_handle {
     char* persist = nullptr; size_t persist_bytes = 0;
     float *x4 = nullptr, *silu_temb = nullptr, *tembias = nullptr, *t_dev = nullptr;
     float2 *Y = nullptr, *X = nullptr, *Xmean = nullptr, *score = nullptr, *xin = nullptr;
+    float2 *cond_buf = nullptr;
+    float2 *Cond = nullptr;                      // score conditioning of the sampler: == Y unless use_sample_cond gave another
     float *lang_partial = nullptr, *lang_step = nullptr;
     unsigned long long* rng_state = nullptr;
     int lang_blocks = 0;
@@ -678,7 +680,7 @@ static void run_sampler(use_handle* h, const float2* noise, hipStream_t s, int i
         const float t = h->timesteps[i];
         const float* temb = h->temb_table + (size_t)i * h->dense_rows;
         for (int k = 0; k < ncorr; ++k) {
-            run_score(h, h->X, h->Y, temb, 0, h->ts_dev + i, 0, h->score, s);
+            run_score(h, h->X, h->Cond, temb, 0, h->ts_dev + i, 0, h->score, s);
             RngRef rr{h->rng_state, d};
             if (sc.corrector == USE_CORR_LANGEVIN) {
                 launch_langevin_norms(h->score, nz(d), rr, h->lang_partial, h->B, n_per_b, h->lang_blocks, s);
@@ -693,7 +695,7 @@ static void run_sampler(use_handle* h, const float2* noise, hipStream_t s, int i
         if (sc.predictor == USE_PRED_NONE) {
             if (i == sc.N - 1) (void)hipMemcpyAsync(h->Xmean, h->X, (size_t)n * 8, hipMemcpyDeviceToDevice, s);
         } else {
-            run_score(h, h->X, h->Y, temb, 0, h->ts_dev + i, 0, h->score, s);
+            run_score(h, h->X, h->Cond, temb, 0, h->ts_dev + i, 0, h->score, s);
             float cd, cs, cn; predictor_coeffs(h->cfg, sc.predictor, t, sc.N, cd, cs, cn);
             launch_predictor(h->X, h->Y, h->score, nz(d), RngRef{h->rng_state, d}, cd, cs, cn, h->X,
                              i == sc.N - 1 ? h->Xmean : nullptr, n, s);
@@ -976,12 +978,13 @@ int use_plan(use_handle* h, int B, int Tpad) {
     size_t off = 0;
     auto take = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; size_t o = off; off += bytes; return o; };
     const size_t o_x4 = take(n * 16), o_Y = take(n * 8), o_X = take(n * 8), o_Xm = take(n * 8), o_sc = take(n * 8),
-                 o_xin = take(n * 8), o_st = take((size_t)B * 4 * h->cfg.nf * 4), o_tb = take((size_t)B * h->dense_rows * 4),
+                 o_xin = take(n * 8), o_cond = take(n * 8), o_st = take((size_t)B * 4 * h->cfg.nf * 4), o_tb = take((size_t)B * h->dense_rows * 4),
                  o_t = take((size_t)B * 4), o_lp = take((size_t)B * h->lang_blocks * 2 * 4), o_ls = take(256), o_rng = take(256);
     h->persist_bytes = off;
     if (hipMalloc((void**)&h->persist, off) != hipSuccess) return fail(USE_E_NOMEM, "cannot allocate %.1f MB of state", off / 1e6);
     h->x4 = (float*)(h->persist + o_x4); h->Y = (float2*)(h->persist + o_Y); h->X = (float2*)(h->persist + o_X);
     h->Xmean = (float2*)(h->persist + o_Xm); h->score = (float2*)(h->persist + o_sc); h->xin = (float2*)(h->persist + o_xin);
+    h->cond_buf = (float2*)(h->persist + o_cond); h->Cond = h->Y;
     h->silu_temb = (float*)(h->persist + o_st); h->tembias = (float*)(h->persist + o_tb); h->t_dev = (float*)(h->persist + o_t);
     h->lang_partial = (float*)(h->persist + o_lp); h->lang_step = (float*)(h->persist + o_ls);
     h->rng_state = (unsigned long long*)(h->persist + o_rng);
@@ -1103,12 +1106,21 @@ int use_get_timesteps(use_handle* h, float* out, int n) {
 }
 
 int use_sample(use_handle* h, const void* y, const void* noise, uint64_t seed, void* out, use_stream_t stream) {
+    return use_sample_cond(h, y, nullptr, noise, seed, out, stream);
+}
+
+int use_sample_cond(use_handle* h, const void* y, const void* cond, const void* noise, uint64_t seed, void* out, use_stream_t stream) {
     int rc = check_ready(h); if (rc) return rc;
     if (!h->sampler_set) return fail(USE_E_STATE, "use_set_sampler has not been called");
     if (!y || !out) return fail(USE_E_INVALID, "null tensor");
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)h->B * h->cfg.n_freq * h->T;
     HIPCHK(hipMemcpyAsync(h->Y, y, n * 8, hipMemcpyDeviceToDevice, s));
+    {   // the conditioning spectrogram the network sees beside x: the SDE's y itself, or a separate one (condition="denoised")
+        float2* want = cond ? h->cond_buf : h->Y;
+        if (want != h->Cond) { HIPCHK(hipStreamSynchronize(s)); drop_graphs(h); h->Cond = want; }    // captured graphs hold the pointer
+        if (cond) HIPCHK(hipMemcpyAsync(h->cond_buf, cond, n * 8, hipMemcpyDeviceToDevice, s));
+    }
     hipLaunchKernelGGL(set_rng_kernel, dim3(1), dim3(1), 0, s, h->rng_state, (unsigned long long)seed, 0ull);
     if (!h->sc.use_graph) {
         run_sampler(h, (const float2*)noise, s, 0, h->sc.N);

@@ -260,9 +260,12 @@ class HipScoreEngine:
         check(self.L.use_get_timesteps(self.h, buf, n))
         return np.array(buf[:], dtype=np.float32)
 
-    def sample(self, y: torch.Tensor, noise: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
-        """Run the configured PC sampler on y (complex64 [B,1,F,T']); returns x_mean of the last step."""
+    def sample(self, y: torch.Tensor, noise: Optional[torch.Tensor] = None, seed: int = 0,
+               cond: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Run the configured PC sampler on y (complex64 [B,1,F,T']); returns x_mean of the last step.  ``cond``: score
+        conditioning when it is not y itself (``use_sample_cond``)."""
         y = _require_cuda_c64("y", y)
+        cptr = None if cond is None or cond is y else _require_cuda_c64("cond", cond, y.shape).data_ptr()
         if (y.shape[0], y.shape[3]) != self.plan_shape:
             raise UseHipError(f"sampler planned for {self.plan_shape}, got B={y.shape[0]} T'={y.shape[3]}")
         nptr = None
@@ -270,7 +273,8 @@ class HipScoreEngine:
             noise = _require_cuda_c64("noise", noise, (self.num_noise_draws(),) + tuple(y.shape))
             nptr = noise.data_ptr()
         out = torch.empty_like(y)
-        check(self.L.use_sample(self.h, y.data_ptr(), nptr, int(seed) & (2**64 - 1), out.data_ptr(), _stream_ptr(y.device)), "use_sample")
+        check(self.L.use_sample_cond(self.h, y.data_ptr(), cptr, nptr, int(seed) & (2**64 - 1), out.data_ptr(), _stream_ptr(y.device)),
+              "use_sample_cond")
         return out
 
     def debug_tensor(self, name: str) -> torch.Tensor:

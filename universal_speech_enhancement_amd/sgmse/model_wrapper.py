@@ -51,13 +51,14 @@ class ScoreModel(SpectralGlue, nn.Module):
 
     # ---- samplers (reference :210-260) -------------------------------------------------------------------
     def fused_sample(self, y, N, predictor, corrector, corrector_steps, snr, t_eps, noise=None, seed=0, use_graph=True,
-                     sde=None):
-        """Whole PC loop inside libuse_hip.so (``use_sample``), with the OUVE constants of ``sde`` (default: ``self.sde``)."""
+                     sde=None, cond=None):
+        """Whole PC loop inside libuse_hip.so (``use_sample_cond``), with the OUVE constants of ``sde`` (default: ``self.sde``);
+        ``cond``: the score conditioning when it is not ``y`` itself."""
         sde = self.sde if sde is None else sde
         eng = self.score_net.engine(y.shape[2], y.device, sde_constants=(sde.theta, sde.sigma_min, sde.sigma_max))
         eng.plan(y.shape[0], y.shape[3])
         eng.set_sampler(N, predictor, corrector, corrector_steps, snr, t_eps, use_graph=use_graph)
-        return eng.sample(y, noise=noise, seed=seed)
+        return eng.sample(y, noise=noise, seed=seed, cond=cond)
 
     def get_pc_sampler(self, predictor_name, corrector_name, y, N=None, minibatch=None, **kwargs):
         N = self.sde.N if N is None else N
@@ -88,16 +89,31 @@ class ScoreModel(SpectralGlue, nn.Module):
         y = batch["perturbed"]
         T_orig = y.size(1)
         Y = self._spectrogram(y)
-        if self.condition != "noisy":
+        Y_denoised = self._spectrogram(batch["fake"]) if "fake" in batch else None
+        # conditioning (reference :283-291): the spectrogram(s) the network sees beside x
+        if self.condition == "noisy":
+            score_conditioning = [Y]
+        elif self.condition == "denoised" and Y_denoised is not None:
+            score_conditioning = [Y_denoised]
+        elif self.condition == "both" and Y_denoised is not None:
+            raise NotImplementedError("condition='both' needs the 6-channel network input, which libuse_hip.so does not implement "
+                                      "(no shipped config selects it; 'noisy' and 'denoised' are served)")
+        else:
             raise NotImplementedError(f"Don't know the conditioning you have wished for: {self.condition}")
-        if self.sde_input != "noisy":
+        # the SDE's y (reference :293-300)
+        if self.sde_input == "denoised" and Y_denoised is not None:
+            sde_input = Y_denoised
+        elif self.sde_input == "noisy":
+            sde_input = Y
+        else:
             raise NotImplementedError(f"Don't know the sde input you have wished for: {self.sde_input}")
         if sampler_type != "pc":
             raise NotImplementedError(f"{sampler_type} is not a valid sampler type!")
-        sampler = self.get_pc_sampler(self.predictor, self.corrector, Y, N=N, corrector_steps=corrector_steps, snr=snr,
-                                      intermediate=False, conditioning=[Y], noise=noise, seed=seed)
+        sampler = self.get_pc_sampler(self.predictor, self.corrector, sde_input, N=N, corrector_steps=corrector_steps, snr=snr,
+                                      intermediate=False, conditioning=score_conditioning, noise=noise, seed=seed)
         sample, nfe = sampler()
-        batch["enhanced"] = self._waveform(sample, T_orig)
+        # reference :320-328: the key depends on what the SDE started from
+        batch["fake_sde_enhanced" if (self.sde_input == "denoised" and Y_denoised is not None) else "enhanced"] = self._waveform(sample, T_orig)
         return batch
 
     @torch.no_grad()
