@@ -130,8 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv_v5_kernel(ConvArgs p) {
     // GroupNorm affine (a, b) of every input channel of this batch item: copied to LDS once, so that the per-chunk reads are
     // LDS reads (lgkmcnt) and do not queue behind the weight DMA on the vector-memory counter
     float2* const coef_lds = reinterpret_cast<float2*>(smem + COEF_OFF);
-    for (int c = tid; c < Ctot; c += 256)
-        coef_lds[c] = p.coef ? *reinterpret_cast<const float2*>(p.coef + ((size_t)b * Ctot + c) * 2) : make_float2(1.f, 0.f);
+    gn_fill_table(coef_lds, p, b, Ctot, tid, 256);
     float ca[VEC], cb[VEC];                                  // GroupNorm affine of the chunk being staged
     auto load_coef = [&](int chunk) {
         const float4* cf = reinterpret_cast<const float4*>(coef_lds + chunk * CK + part * VEC);
@@ -430,10 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv_v5_kernel(ConvArgs p) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
             const int co = n0 + tid;
-            if (co < p.Cout) {
-                float* dst = p.stats + (((size_t)b * ntile + tile) * p.Cout + co) * 2;
-                dst[0] = s; dst[1] = q;
-            }
+            if (co < p.Cout) gn_accumulate(p.stats + ((size_t)b * p.Cout + co) * 2, s, q);
         }
     }
     V5_STAMP(8)

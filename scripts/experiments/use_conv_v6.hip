@@ -110,8 +110,7 @@ __global__ __launch_bounds__(512) void conv_v6_kernel(ConvArgs p) {
     // reads (short-lived registers, lgkmcnt) instead of 16 registers that live across the whole chunk
     constexpr int COEF_OFF = W_OFF + 2 * WROW_BYTES;         // [<= 512 channels][2] floats behind the weight buffers
     float2* const coef_lds = reinterpret_cast<float2*>(smem + COEF_OFF);
-    for (int c = tid; c < Ctot; c += 512)
-        coef_lds[c] = p.coef ? *reinterpret_cast<const float2*>(p.coef + ((size_t)b * Ctot + c) * 2) : make_float2(1.f, 0.f);
+    gn_fill_table(coef_lds, p, b, Ctot, tid, 512);
     float ca[VEC], cb[VEC];                                  // GroupNorm affine of the piece being transformed
     auto load_coef = [&](int chunk) {
         const float4* cf = reinterpret_cast<const float4*>(coef_lds + chunk * CK + part * VEC);
@@ -425,10 +424,7 @@ __global__ __launch_bounds__(512) void conv_v6_kernel(ConvArgs p) {
 #pragma unroll
             for (int w = 0; w < 8; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
             const int co = n0 + tid;
-            if (co < p.Cout) {
-                float* dst = p.stats + (((size_t)b * gridDim.x + tile) * p.Cout + co) * 2;
-                dst[0] = s; dst[1] = q;
-            }
+            if (co < p.Cout) gn_accumulate(p.stats + ((size_t)b * p.Cout + co) * 2, s, q);
         }
     }
 }

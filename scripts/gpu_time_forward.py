@@ -15,6 +15,8 @@ from universal_speech_enhancement_amd.hip_engine import set_option
 for env, opt in (("USE_SUBBATCH", "subbatch"), ("USE_STAGGER", "stagger_level")):      # A/B of the scheduling knobs
     if os.environ.get(env):
         set_option(opt, int(os.environ[env]))
+for kv in filter(None, os.environ.get("USE_OPTS", "").split(",")):                       # generic: USE_OPTS="gn_inline=0,subbatch=2"
+    set_option(kv.split("=")[0], int(kv.split("=")[1]))
 eng = HipScoreEngine(precision=prec)
 eng.load_state_dict(tw.make_state_dict(1234, **tw.LARGE))
 x = torch.from_numpy(tn.complex_normal(1, "x", (B, 1, 512, T))).cuda() * 0.5

@@ -456,8 +456,9 @@ def test_minibatch_sampler_and_enhance(sd_np):
     z = torch.from_numpy(tnoise.sampler_noise(6, 1 + 2 * 2, (1, 1, 512, 64))).cuda()
     x_hat = m.enhance(y1, predictor="reverse_diffusion", corrector="ald", N=2, corrector_steps=1, snr=0.5, noise=z)
     assert x_hat.shape == (9600,) and not x_hat.is_cuda and torch.isfinite(x_hat).all()
-    ref = m.sample({"perturbed": y1 / y1.abs().max()}, N=2, corrector_steps=1, snr=0.5, noise=z)   # corrector of m: ald
-    assert _relmax(x_hat, ref["enhanced"][0].cpu() * float(y1.abs().max())) < 1e-5
+    nf = y1.abs().max().item()                                # (division by the Python float, as enhance() does: a tensor divisor
+    ref = m.sample({"perturbed": y1 / nf}, N=2, corrector_steps=1, snr=0.5, noise=z)   # differs in the last bit of some samples)
+    assert _relmax(x_hat, ref["enhanced"][0].cpu() * nf) < 1e-6
     x_hat2, nfe2, rtf = m.enhance(y1, corrector="ald", N=1, timeit=True)
     assert nfe2 == 2 and rtf > 0
     X, Yc, T_orig, nf = m.enhance(y1, corrector="ald", N=1, return_stft=True)

@@ -145,15 +145,15 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
         pdst[j] = idx < NPIECE ? hy * HPITCH + hx * ROWB + part * 16 : -1;
     }
     const int dummy_off = MAIN_BYTES + tid * 16;
+    // GroupNorm affine (a, b) of every input channel of this item in LDS: finalised here from the producers' totals (or copied
+    // from a coefficient array, or the identity) - no separate finalize launch, and the per-chunk reads are LDS reads
+    constexpr int COEF_OFF = MAIN_BYTES + 512 * 16;
+    float2* const coef_lds = reinterpret_cast<float2*>(smem + COEF_OFF);   // filled in the prologue, behind the first loads
     float ca[VEC], cb[VEC];                                  // GroupNorm affine of the chunk being staged
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) { ca[k] = 1.f; cb[k] = 0.f; }
     auto load_coef = [&](int chunk) {
-        if (p.coef) {
-            const float* cf = p.coef + ((size_t)b * Ctot + chunk * CK + part * VEC) * 2;
+        const float2* cf = coef_lds + chunk * CK + part * VEC;
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) { ca[k] = cf[2 * k]; cb[k] = cf[2 * k + 1]; }
-        }
+        for (int k = 0; k < VEC; ++k) { const float2 v = cf[k]; ca[k] = v.x; cb[k] = v.y; }
     };
     // Global loads of the main loop are buffer loads: a 4-SGPR descriptor of the tensor, a uniform SGPR offset and a 32-bit
     // per-lane VGPR offset - half the address traffic of a 64-bit-pointer global_load per issue.
@@ -218,6 +218,8 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
         V2_LOAD_W(0, 1, wa0, wa1);                           // weights of iteration 1, stored by LDS(0)
 #pragma unroll
         for (int j = 0; j < PIECE_ITERS; ++j) raw[j] = src_ld0(0, ppix[j]);
+        gn_fill_table(coef_lds, p, b, Ctot, tid, 512);       // while the halo / weight loads are in flight
+        __syncthreads();                                     // coef_lds complete
         load_coef(0);
         V2_STORE_W(0, w00, w01);
 #pragma unroll
@@ -478,10 +480,7 @@ __global__ __launch_bounds__(512) void conv_v2_kernel(ConvArgs p) {
 #pragma unroll
             for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
             const int co = n0 + tid;
-            if (co < p.Cout) {
-                float* dst = p.stats + (((size_t)b * gridDim.x + tile) * p.Cout + co) * 2;
-                dst[0] = s; dst[1] = q;
-            }
+            if (co < p.Cout) gn_accumulate(p.stats + ((size_t)b * p.Cout + co) * 2, s, q);
         }
     }
     V2_STAMP(5)
@@ -491,7 +490,7 @@ template <typename TIN, typename TOUT, int CK, bool ACT>
 static void v2_launch_t(const ConvArgs& a, hipStream_t s) {
     constexpr int ROWB = CK * (int)sizeof(TIN) + 16;
     constexpr int HPITCH = (V2_HE * ROWB / 16 + 15) / 16 * 16 * 16;
-    constexpr int MAIN = 2 * V2_HE * HPITCH + 2 * V2_BN * ROWB + 512 * 16;
+    constexpr int MAIN = 2 * V2_HE * HPITCH + 2 * V2_BN * ROWB + 512 * 16 + 1024 * 8;
     constexpr int EPI = 8 * 32 * (64 + 4) * 4 + 4 * V2_BN * 2 * 4;
     constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
     static bool attr_set = false;
@@ -507,7 +506,7 @@ static void v2_launch_t(const ConvArgs& a, hipStream_t s) {
 bool conv_v2_eligible(const ConvArgs& a) {
     const int Ctot = a.C0 + a.C1, XC = a.XC0 + a.XC1;
     const int ck = a.in_dtype == DT_F32 ? 32 : 64;
-    return a.ntaps == 9 && a.Cout > 32 && a.in_dtype == a.out_dtype && Ctot % ck == 0 && XC % ck == 0 &&
+    return a.ntaps == 9 && a.Cout > 32 && a.in_dtype == a.out_dtype && Ctot % ck == 0 && Ctot <= 1024 && XC % ck == 0 &&
            (a.C1 == 0 || a.C0 % ck == 0) && (a.XC1 == 0 || a.XC0 % ck == 0) &&      // a chunk never straddles the two sources
            a.H >= V2_T && a.W >= V2_T;
 }

@@ -109,15 +109,15 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         pdst[j] = idx < NPIECE ? hy * HPITCH + hx * ROWB + part * 16 : -1;
     }
     const int dummy_off = MAIN_BYTES + tid * 16;
+    // GroupNorm affine (a, b) of every input channel of this item in LDS: finalised here from the producers' totals (or copied
+    // from a coefficient array, or the identity) - no separate finalize launch, and the per-chunk reads are LDS reads
+    constexpr int COEF_OFF = MAIN_BYTES + 512 * 16;
+    float2* const coef_lds = reinterpret_cast<float2*>(smem + COEF_OFF);   // filled in the prologue, behind the first loads
     float ca[VEC], cb[VEC];                                  // GroupNorm affine of the chunk being staged
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) { ca[k] = 1.f; cb[k] = 0.f; }
     auto load_coef = [&](int chunk) {
-        if (p.coef) {
-            const float* cf = p.coef + ((size_t)b * Ctot + chunk * CK + part * VEC) * 2;
+        const float2* cf = coef_lds + chunk * CK + part * VEC;
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) { ca[k] = cf[2 * k]; cb[k] = cf[2 * k + 1]; }
-        }
+        for (int k = 0; k < VEC; ++k) { const float2 v = cf[k]; ca[k] = v.x; cb[k] = v.y; }
     };
     // buffer loads: tensor descriptor + uniform SGPR offset + 32-bit lane offset
     auto buf_ld = [&](const void* base, unsigned voff, unsigned soff) -> uint4 {
@@ -173,6 +173,8 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         V4_LOAD_W(0, 1, wa);                                 // stored by LDS(0)
 #pragma unroll
         for (int j = 0; j < PIECE_ITERS; ++j) raw[j] = src_ld0(0, ppix[j]);
+        gn_fill_table(coef_lds, p, b, Ctot, tid, 512);       // while the halo / weight loads are in flight
+        __syncthreads();                                     // coef_lds complete
         load_coef(0);
         V4_STORE_W(0, w0);
 #pragma unroll
@@ -420,10 +422,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
 #pragma unroll
             for (int w = 0; w < 8; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
             const int co = n0 + tid;
-            if (co < p.Cout) {
-                float* dst = p.stats + (((size_t)b * gridDim.x + tile) * p.Cout + co) * 2;
-                dst[0] = s; dst[1] = q;
-            }
+            if (co < p.Cout) gn_accumulate(p.stats + ((size_t)b * p.Cout + co) * 2, s, q);
         }
     }
     V4_STAMP(8)
@@ -432,7 +431,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
 template <typename TIN, typename TOUT, int CK, bool ACT>
 static void v4_launch_t(const ConvArgs& a, hipStream_t s) {
     constexpr int ROWB = CK * (int)sizeof(TIN) + 16;
-    constexpr int MAIN = 2 * V4_HH * V4_HW * ROWB + 2 * V4_BN * ROWB + 512 * 16;
+    constexpr int MAIN = 2 * V4_HH * V4_HW * ROWB + 2 * V4_BN * ROWB + 512 * 16 + 512 * 8;
     constexpr int EPI = 8 * 32 * (V4_BN + 4) * 4 + 8 * V4_BN * 2 * 4;
     constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
     static bool attr_set = false;
@@ -457,7 +456,7 @@ bool conv_v4_eligible(const ConvArgs& a) {
     // (per image, so that the kernel choice - and with it the summation order - does not depend on the batch size)
     const long blocks = (long)conv_v4_tiles(a.H, a.W) * ((a.Cout + V4_BN - 1) / V4_BN);
     return !off && a.wb != nullptr && (XC == 0 || a.w2b != nullptr) && a.ntaps == 9 && a.Cout > 32 && a.in_dtype == a.out_dtype &&
-           Ctot % ck == 0 && XC % ck == 0 && (a.C1 == 0 || a.C0 % ck == 0) && (a.XC1 == 0 || a.XC0 % ck == 0) && a.cout_pad % V4_BN == 0 && a.H % V4_TH == 0 && a.W % V4_TW == 0 && blocks >= g_v4_min_blocks;
+           Ctot % ck == 0 && Ctot <= 512 && XC % ck == 0 && (a.C1 == 0 || a.C0 % ck == 0) && (a.XC1 == 0 || a.XC0 % ck == 0) && a.cout_pad % V4_BN == 0 && a.H % V4_TH == 0 && a.W % V4_TW == 0 && blocks >= g_v4_min_blocks;
 }
 
 void launch_conv_v4(const ConvArgs& a0, hipStream_t s) {

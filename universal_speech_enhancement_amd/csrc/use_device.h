@@ -118,6 +118,43 @@ template <> struct Mfma<float> {
     DEVI static f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// GroupNorm statistics: producers add their per-channel partial sums into [B][C][2] 64-bit fixed-point totals (integer
+// atomics commute, so the result does not depend on the arrival order: bit-reproducible); consumers turn the totals of a
+// channel's group into the affine (a, b) of y = a x + b.  Scales: sums 2^-20, sums of squares 2^-12 per count - absolute
+// resolution far below fp32's on these magnitudes, range |sum| < 8e12, sum of squares < 2e15 per (item, channel).
+// ---------------------------------------------------------------------------------------------------------
+constexpr float GN_SUM_SCALE = 1048576.0f, GN_SQ_SCALE = 4096.0f;
+DEVI void gn_accumulate(long long* dst, float s, float q) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__float2ll_rn(s * GN_SUM_SCALE));
+    atomicAdd(reinterpret_cast<unsigned long long*>(dst + 1), (unsigned long long)__float2ll_rn(q * GN_SQ_SCALE));
+}
+// (a, b) of channel c (of the concatenation [C0 | C1]) of item b
+DEVI float2 gn_coef_of(const long long* __restrict__ st0, int C0, const long long* __restrict__ st1, int C1,
+                       const float* __restrict__ gamma, const float* __restrict__ beta, int groups, float inv_n, float eps,
+                       int b, int c) {
+    const int cpg = (C0 + C1) / groups, g0 = (c / cpg) * cpg;
+    long long S = 0, Q = 0;
+    for (int k = 0; k < cpg; ++k) {
+        const int cc = g0 + k;
+        const long long* p = cc < C0 ? st0 + ((size_t)b * C0 + cc) * 2 : st1 + ((size_t)b * C1 + (cc - C0)) * 2;
+        S += p[0]; Q += p[1];
+    }
+    const double mean = (double)S * (1.0 / 1048576.0) * (double)inv_n;
+    double var = (double)Q * (1.0 / 4096.0) * (double)inv_n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float a = gamma[c] * rstd;
+    return make_float2(a, beta[c] - (float)mean * a);
+}
+// coefficient table of one item's input channels in LDS (every conv consumer builds it in its prologue)
+template <typename ARGS>
+DEVI void gn_fill_table(float2* tab, const ARGS& p, int b, int Ctot, int tid, int nthreads) {
+    for (int c = tid; c < Ctot; c += nthreads)
+        tab[c] = p.gn_st0 ? gn_coef_of(p.gn_st0, p.C0, p.gn_st1, p.C1, p.gn_gamma, p.gn_beta, p.gn_groups, p.gn_inv_n, p.gn_eps, b, c)
+                 : p.coef ? *reinterpret_cast<const float2*>(p.coef + ((size_t)b * Ctot + c) * 2) : make_float2(1.f, 0.f);
+}
+
 // Sum over the lanes {l, l+S, l+2S, ...} of a wave (S = 4, 8 or 16) with VALU cross-lane ops only (DPP row rotate,
 // v_permlane16_swap, v_permlane32_swap) -- no LDS round trips (ds_bpermute) on the epilogue's critical path.
 template <int S>

@@ -83,7 +83,7 @@ struct Expected { std::string name; std::vector<int64_t> shape; };
 
 constexpr int MAX_SUB = 4;                       // sub-batches of the pipelined evaluation (run_score)
 
-struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, dtype = DT_F32; float* stats = nullptr; int ntiles = 0; };
+struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, dtype = DT_F32; long long* stats = nullptr; };   // stats: [B][C][2] fixed-point totals
 
 struct Arena {
     char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
@@ -138,6 +138,7 @@ struct use_handle {
     // the first reaches its small feature maps, so that one half's latency-bound kernels hide behind the other's large ones
     int nsub = 1, sub_B[MAX_SUB] = {0, 0, 0, 0};  // sub-batch sizes (nsub = 1: not split)
     Arena sub_arena[MAX_SUB];                    // workspaces of sub-batches 1.. (inside the same allocation as `arena`)
+    Arena st_arena[MAX_SUB];                     // per sub-batch: the GroupNorm totals of all its activations, contiguous (one memset per evaluation)
     hipStream_t aux_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_stagger[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr},
                ev_join[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
@@ -381,6 +382,10 @@ static int pack_all(use_handle* h, char* blob) {
 // forward pass (one score-network evaluation)
 // ---------------------------------------------------------------------------------------------------------
 static int g_subbatch = 2;                       // use_set_option("subbatch", n): sub-batches per evaluation (0/1: off)
+// GroupNorm finalisation inside the consuming conv (no launch) for maps of at most g_gn_inline pixels per item, a separate
+// finalize launch above: on the large maps thousands of workgroups would each redo the finalisation (measured slower), on the
+// small, latency-bound maps the saved launch is what counts.  use_set_option("gn_inline", pixels); 0: never inline
+static long g_gn_inline = 128L * 160L;
 static int g_stagger_level = 2;                  // use_set_option("stagger_level", l): the next sub-batch starts after level l
 
 struct Fwd {
@@ -389,6 +394,7 @@ struct Fwd {
     const float* t; int t_stride;                 // per-item time (stride 0: shared)
     int B = 0;                                    // items of this (sub-)batch
     Arena* arena = nullptr;                       // its activation workspace
+    Arena* st_arena = nullptr;                    // its GroupNorm-totals region
     bool primary = true;                          // the first sub-batch owns the FLOP count and the debug tensors
     hipEvent_t ev_stagger = nullptr;              // recorded when the large maps of the down path are done (or null)
     template <typename T> const T* W(size_t off) const { return (const T*)(h->blob + off); }
@@ -396,31 +402,40 @@ struct Fwd {
     Act new_act(int C, int H, int Wd, int dtype, bool stats) {
         Act a; a.C = C; a.H = H; a.W = Wd; a.dtype = dtype;
         a.p = arena->alloc((size_t)B * H * Wd * C * dtype_size(dtype));
-        if (stats) a.stats = (float*)arena->alloc((size_t)B * tiles_per_image(H, Wd) * C * 2 * 4);
+        if (stats) a.stats = (long long*)st_arena->alloc((size_t)B * C * 2 * sizeof(long long));
         return a;
     }
 
+    // coefficient array for the consumers that cannot finalise the GroupNorm themselves (the FIR resampling kernels)
     float* gn_coef(const Act& a, const Act* a2, const GNW& g) {
         const int C = a.C + (a2 ? a2->C : 0);
         float* coef = (float*)arena->alloc((size_t)B * C * 2 * 4);
         if (!h->dry)
-            launch_gn_finalize(a.stats, a.C, a.ntiles, a2 ? a2->stats : nullptr, a2 ? a2->C : 0, a2 ? a2->ntiles : 0,
-                               W<float>(g.g_off), W<float>(g.b_off), std::min(C / 4, 32), a.H * a.W, 1e-6f, coef,
-                               B, s);
+            launch_gn_finalize(a.stats, a.C, a2 ? a2->stats : nullptr, a2 ? a2->C : 0, W<float>(g.g_off), W<float>(g.b_off),
+                               std::min(C / 4, 32), a.H * a.W, 1e-6f, coef, B, s);
         return coef;
     }
 
-    Act conv(const Act& a, const Act* a2, const float* coef, int act, const ConvW& w, const float* temb,
+    // gn != null: the input concat(a, a2) goes through this GroupNorm, finalised inside the conv kernel from the producers' totals
+    Act conv(const Act& a, const Act* a2, const GNW* gn, int act, const ConvW& w, const float* temb,
              const Act* res, float scale, const float* pyr, const CombineW* cb, int out_dtype, bool stats,
              const Act* sx0 = nullptr, const Act* sx1 = nullptr, const ConvW* w2 = nullptr, size_t bias_off = 0) {
         Act o = new_act(w.cout, a.H, a.W, out_dtype, stats);
         double fl = 2.0 * B * a.H * a.W * (double)w.cout * w.cin * w.ntaps;
         if (w2) fl += 2.0 * B * a.H * a.W * (double)w2->cout * w2->cin;
         h->flops += fl;
+        // large maps: separate finalize launch into a coefficient array (allocated in the dry run as well: the arena is sized by it)
+        const float* coef_arr = (gn && (long)a.H * a.W > g_gn_inline) ? gn_coef(a, a2, *gn) : nullptr;
         if (h->dry) return o;
         ConvArgs p{};
         p.src0 = a.p; p.C0 = a.C; p.src1 = a2 ? a2->p : nullptr; p.C1 = a2 ? a2->C : 0; p.in_dtype = a.dtype;
-        p.coef = coef; p.act = act; p.w = h->blob + w.w_off; p.cout_pad = w.cout_pad;
+        p.coef = coef_arr; p.act = act; p.w = h->blob + w.w_off; p.cout_pad = w.cout_pad;
+        if (gn && !coef_arr) {
+            const int C = a.C + (a2 ? a2->C : 0), groups = std::min(C / 4, 32);
+            p.gn_st0 = a.stats; p.gn_st1 = a2 ? a2->stats : nullptr;
+            p.gn_gamma = W<float>(gn->g_off); p.gn_beta = W<float>(gn->b_off); p.gn_groups = groups;
+            p.gn_inv_n = 1.0f / ((float)(C / groups) * (float)(a.H * a.W)); p.gn_eps = 1e-6f;
+        }
         p.wb = w.has_wb ? h->blob + w.wb_off : nullptr;
         p.bias = W<float>(w2 ? bias_off : w.b_off);
         if (w2) { p.x0 = sx0->p; p.XC0 = sx0->C; p.x1 = sx1 ? sx1->p : nullptr; p.XC1 = sx1 ? sx1->C : 0; p.w2 = h->blob + w2->w_off;
@@ -430,7 +445,6 @@ struct Fwd {
         p.pyr = pyr; p.w4 = cb ? W<float>(cb->w_off) : nullptr; p.b4 = cb ? W<float>(cb->b_off) : nullptr;
         p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
         p.B = B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
-        o.ntiles = conv_out_tiles(p);
         const bool main_variant = conv_v4_eligible(p);        // the dominant kernel (conv_v4_kernel, large maps)
         if (h->profile && (main_variant || (h->profile_all && conv_v2_eligible(p)))) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -446,7 +460,7 @@ struct Fwd {
                 if (pyr) by += px * 4 * 4;
                 h->prof_bytes.push_back(by);
             }
-            char d[160]; snprintf(d, sizeof d, "%-28s H=%3d W=%3d Cin=%3d Cout=%3d taps=%d gn=%d res=%d sc=%d", w.wname.c_str(), a.H, a.W, w.cin, w.cout, w.ntaps, coef != nullptr, res != nullptr, w2 ? w2->cin : 0);
+            char d[160]; snprintf(d, sizeof d, "%-28s H=%3d W=%3d Cin=%3d Cout=%3d taps=%d gn=%d res=%d sc=%d", w.wname.c_str(), a.H, a.W, w.cin, w.cout, w.ntaps, gn != nullptr, res != nullptr, w2 ? w2->cin : 0);
             h->prof_desc.push_back(d);
         } else {
             launch_conv(p, s);
@@ -458,7 +472,6 @@ struct Fwd {
     Act resblock(const Act& x, const Act* skip, const ResW& r, const float* pyr = nullptr, const CombineW* cb = nullptr) {
         const float rs = 0.70710678118654752440f;   // 1/sqrt(2)
         const float* temb = tembias ? tembias + r.dense_row0 : nullptr;    // unconditional: no Dense_0(temb) term
-        float* coef0 = gn_coef(x, skip, r.gn0);
         const int dt = h->act_dtype;
         Act hcur, xr;
         const Act* sx0 = &x; const Act* sx1 = skip;          // inputs of the 1x1 shortcut (Conv_2)
@@ -466,6 +479,7 @@ struct Fwd {
             const int H2 = r.up ? x.H * 2 : x.H / 2, W2 = r.up ? x.W * 2 : x.W / 2;
             Act hr = new_act(x.C, H2, W2, dt, false);
             xr = new_act(x.C, H2, W2, dt, false);
+            float* coef0 = gn_coef(x, skip, r.gn0);          // the resampling kernels take the GroupNorm as a coefficient array
             if (!h->dry) {
                 if (r.up) launch_fir_up2(x.p, dt, coef0, 1, hr.p, xr.p, B, x.H, x.W, x.C, s);
                 else      launch_fir_down2(x.p, dt, coef0, 1, hr.p, xr.p, B, x.H, x.W, x.C, s);
@@ -473,21 +487,19 @@ struct Fwd {
             hcur = conv(hr, nullptr, nullptr, 0, r.c0, temb, nullptr, 1.f, nullptr, nullptr, dt, true);
             sx0 = &xr; sx1 = nullptr;
         } else {
-            hcur = conv(x, skip, coef0, 1, r.c0, temb, nullptr, 1.f, nullptr, nullptr, dt, true);
+            hcur = conv(x, skip, &r.gn0, 1, r.c0, temb, nullptr, 1.f, nullptr, nullptr, dt, true);
         }
-        float* coef1 = gn_coef(hcur, nullptr, r.gn1);
         if (r.has_c2)   // Conv_1 and the Conv_2 shortcut accumulate into the same MFMA tile (one K loop)
-            return conv(hcur, nullptr, coef1, 1, r.c1, nullptr, nullptr, rs, pyr, cb, dt, true, sx0, sx1, &r.c2, r.b12_off);
-        return conv(hcur, nullptr, coef1, 1, r.c1, nullptr, &x, rs, pyr, cb, dt, true);
+            return conv(hcur, nullptr, &r.gn1, 1, r.c1, nullptr, nullptr, rs, pyr, cb, dt, true, sx0, sx1, &r.c2, r.b12_off);
+        return conv(hcur, nullptr, &r.gn1, 1, r.c1, nullptr, &x, rs, pyr, cb, dt, true);
     }
 
     // AttnBlockpp.forward (reference layerspp.py:77-93)
     Act attention(const Act& x, const AttnW& aw) {
         const int dt = h->act_dtype;
-        float* coef = gn_coef(x, nullptr, aw.gn);
-        Act q = conv(x, nullptr, coef, 0, aw.q, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
-        Act k = conv(x, nullptr, coef, 0, aw.k, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
-        Act v = conv(x, nullptr, coef, 0, aw.v, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
+        Act q = conv(x, nullptr, &aw.gn, 0, aw.q, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
+        Act k = conv(x, nullptr, &aw.gn, 0, aw.k, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
+        Act v = conv(x, nullptr, &aw.gn, 0, aw.v, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
         Act a = new_act(x.C, x.H, x.W, dt, false);
         const int N = x.H * x.W;
         const int ck = dt == DT_F32 ? 32 : 64;
@@ -531,6 +543,8 @@ struct Fwd {
         const use_config& c = H->cfg;
         const int L = c.n_levels, nrb = c.num_res_blocks, dt = H->act_dtype;
         arena->reset();
+        st_arena->reset();
+        if (!H->dry && st_arena->base) (void)hipMemsetAsync(st_arena->base, 0, st_arena->cap, s);   // all GroupNorm totals of this evaluation
         if (primary) { H->flops = 0.0; H->debug.clear(); H->debug_B = B; }
         Act xin; xin.p = (void*)x4; xin.C = 4; xin.H = c.n_freq; xin.W = H->T; xin.dtype = DT_F32;
         std::vector<Act> hs;
@@ -561,14 +575,13 @@ struct Fwd {
                 hc = resblock(hc, &sk, H->res[ri++]);
             }
             const PyrW& pw = H->pyrs[pi++];
-            float* coef = gn_coef(hc, nullptr, pw.gn);
             if (!have_pyr) {
-                pyr = conv(hc, nullptr, coef, 1, pw.conv, nullptr, nullptr, 1.f, nullptr, nullptr, DT_F32, false);
+                pyr = conv(hc, nullptr, &pw.gn, 1, pw.conv, nullptr, nullptr, 1.f, nullptr, nullptr, DT_F32, false);
                 have_pyr = true;
             } else {
                 Act up = new_act(4, pyr.H * 2, pyr.W * 2, DT_F32, false);               // pyramid_upsample
                 if (!H->dry) launch_fir_up2(pyr.p, DT_F32, nullptr, 0, nullptr, up.p, B, pyr.H, pyr.W, 4, s);
-                pyr = conv(hc, nullptr, coef, 1, pw.conv, nullptr, &up, 1.f, nullptr, nullptr, DT_F32, false);
+                pyr = conv(hc, nullptr, &pw.gn, 1, pw.conv, nullptr, &up, 1.f, nullptr, nullptr, DT_F32, false);
             }
             if (lvl != 0) hc = resblock(hc, nullptr, H->res[ri++]);
         }
@@ -597,7 +610,7 @@ static void run_score(use_handle* h, const float2* x, const float2* y, const flo
     const float* outw = (const float*)(h->blob + h->outw_off); const float* outb = (const float*)(h->blob + h->outb_off);
     if (h->nsub == 1) {
         Fwd f0{h, s, tembias, temb_bstride, t, t_stride};
-        f0.B = h->B; f0.arena = &h->arena;
+        f0.B = h->B; f0.arena = &h->arena; f0.st_arena = &h->st_arena[0];
         Act pyr = f0.run(h->x4);
         launch_score_out((const float*)pyr.p, t, t_stride, outw, outb, out, h->B, n_per_b, sign, s);
         return;
@@ -617,7 +630,7 @@ static void run_score(use_handle* h, const float2* x, const float2* y, const flo
         }
         Fwd f{h, si, tembias ? tembias + (size_t)b0 * temb_bstride : nullptr, temb_bstride,
               t ? t + (size_t)b0 * t_stride : nullptr, t_stride};
-        f.B = h->sub_B[i]; f.arena = i ? &h->sub_arena[i] : &h->arena; f.primary = i == 0;
+        f.B = h->sub_B[i]; f.arena = i ? &h->sub_arena[i] : &h->arena; f.st_arena = &h->st_arena[i]; f.primary = i == 0;
         if (overlap && i + 1 < h->nsub) f.ev_stagger = h->ev_stagger[i];
         Act pyr = f.run(h->x4 + (size_t)b0 * n_per_b * 4);
         launch_score_out((const float*)pyr.p, t ? t + (size_t)b0 * t_stride : nullptr, t_stride, outw, outb,
@@ -736,6 +749,7 @@ int use_set_option(const char* name, long long value) {
     if (!name) return fail(USE_E_INVALID, "option name is null");
     if (!strcmp(name, "subbatch")) { g_subbatch = (int)value; return USE_OK; }          // takes effect at the next use_plan
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
+    if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
 #ifdef USE_HIP_EXPERIMENTS
     if (!strcmp(name, "conv_v5_min_blocks")) { conv_v5_set_min_blocks((long)value); return USE_OK; }
@@ -945,14 +959,15 @@ int use_plan(use_handle* h, int B, int Tpad) {
     if (h->arena.base) { HIPCHK(hipFree(h->arena.base)); h->arena.base = nullptr; }
     h->arena = Arena{};
     h->dry = true;
-    size_t caps[MAX_SUB] = {0, 0, 0, 0}, total = 0;
+    size_t caps[MAX_SUB] = {0, 0, 0, 0}, stcaps[MAX_SUB] = {0, 0, 0, 0}, total = 0;
     for (int i = 0; i < h->nsub; ++i) {
         Arena& ar = i ? h->sub_arena[i] : h->arena;
-        ar = Arena{};
+        ar = Arena{}; h->st_arena[i] = Arena{};
         Fwd f{h, nullptr, nullptr, 0, nullptr, 0};
-        f.B = h->sub_B[i]; f.arena = &ar; f.primary = i == 0;
+        f.B = h->sub_B[i]; f.arena = &ar; f.st_arena = &h->st_arena[i]; f.primary = i == 0;
         f.run(nullptr);
         caps[i] = (ar.peak + 4096 + 255) & ~(size_t)255; total += caps[i];
+        stcaps[i] = (h->st_arena[i].peak + 255) & ~(size_t)255; total += stcaps[i];
     }
     h->dry = false;
     char* base = nullptr;
@@ -962,6 +977,7 @@ int use_plan(use_handle* h, int B, int Tpad) {
     {
         size_t off = caps[0];
         for (int i = 1; i < h->nsub; ++i) { h->sub_arena[i].base = base + off; h->sub_arena[i].cap = caps[i]; off += caps[i]; }
+        for (int i = 0; i < h->nsub; ++i) { h->st_arena[i].base = base + off; h->st_arena[i].cap = stcaps[i]; off += stcaps[i]; }
     }
     if (h->nsub > 1 && !h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < h->nsub; ++i) {
@@ -1318,8 +1334,8 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
     const size_t wbytes = (size_t)9 * w.cout_pad * Cin * es, w2bytes = (size_t)w2.cout_pad * std::max(XC, 1) * es;
     char* dw = (char*)dalloc(wbytes); char* dwb = (char*)dalloc(wbytes);
     char* dw2 = XC ? (char*)dalloc(w2bytes) : nullptr; char* dw2b = XC ? (char*)dalloc(w2bytes) : nullptr;
-    const int max_tiles = tiles_per_image(c->H, c->W);       // the finest tiling any kernel uses
-    float* stats = c->stats ? (float*)dalloc((size_t)c->B * max_tiles * c->Cout * 2 * 4) : nullptr;
+    const size_t stats_bytes = (size_t)c->B * c->Cout * 2 * sizeof(long long);
+    long long* stats = c->stats ? (long long*)dalloc(stats_bytes) : nullptr;
     if (!src0 || !out || !outf || !dw || !dwb || (c->stats && !stats)) { cleanup(); return fail(USE_E_NOMEM, "conv bench allocation failed"); }
     fill(src0, px * c->C0, dt, 1, -2.f, 2.f); if (src1) fill(src1, px * c->C1, dt, 2, -2.f, 2.f);
     if (x0) fill(x0, px * c->XC0, dt, 3, -1.f, 1.f); if (x1) fill(x1, px * c->XC1, dt, 4, -1.f, 1.f);
@@ -1368,7 +1384,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
         trace = (unsigned long long*)dalloc(512 * 8);
         if (trace) { (void)hipMemset(trace, 0, 512 * 8); a.trace = trace; a.dbg = atoi(getenv("USE_HIP_TRACE")); }
     }
-    if (stats) (void)hipMemset(stats, 0, (size_t)c->B * max_tiles * c->Cout * 2 * 4);
+    if (stats) (void)hipMemset(stats, 0, stats_bytes);
     if (run() != 0) { cleanup(); return fail(USE_E_INVALID, "variant %d cannot run this case", c->variant); }
     if (hipDeviceSynchronize() != hipSuccess) { cleanup(); return fail(USE_E_HIP, "conv bench: launch failed: %s", hipGetErrorString(hipGetLastError())); }
     if (trace) {
@@ -1393,16 +1409,14 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
         hipLaunchKernelGGL(to_float_kernel, dim3((unsigned)((px * c->Cout + 255) / 256)), dim3(256), 0, 0, out, outf, px * c->Cout, dt);
         if (hipMemcpy(out_host, outf, px * c->Cout * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(USE_E_HIP, "copy back failed");
     }
-    if (stats_host && stats) {                                // per (item, channel) totals: sum over the kernel's tiles
-        const int nt = c->variant == 0 ? conv_out_tiles(a) : c->variant == 5 ? conv_v5_tiles(c->H, c->W) : (c->variant == 4 || c->variant == 6) ? conv_v4_tiles(c->H, c->W) : conv_v2_tiles(c->H, c->W);
-        std::vector<float> hs((size_t)c->B * nt * c->Cout * 2);
-        if (hipMemcpy(hs.data(), stats, hs.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(USE_E_HIP, "copy back failed");
-        for (int b = 0; b < c->B; ++b)
-            for (int co = 0; co < c->Cout; ++co) {
-                double s0 = 0, s1 = 0;
-                for (int t = 0; t < nt; ++t) { s0 += hs[(((size_t)b * nt + t) * c->Cout + co) * 2]; s1 += hs[(((size_t)b * nt + t) * c->Cout + co) * 2 + 1]; }
-                stats_host[((size_t)b * c->Cout + co) * 2] = (float)s0; stats_host[((size_t)b * c->Cout + co) * 2 + 1] = (float)s1;
-            }
+    if (stats_host && stats) {                                // per (item, channel) totals of ONE launch, as floats
+        (void)hipMemset(stats, 0, stats_bytes);
+        run();
+        std::vector<long long> hs((size_t)c->B * c->Cout * 2);
+        if (hipMemcpy(hs.data(), stats, stats_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(USE_E_HIP, "copy back failed");
+        for (size_t i = 0; i < hs.size(); i += 2) {
+            stats_host[i] = (float)((double)hs[i] / 1048576.0); stats_host[i + 1] = (float)((double)hs[i + 1] / 4096.0);
+        }
     }
     cleanup();
     return rc;

@@ -19,10 +19,14 @@ inline int conv_v2_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 15) / 16
 //   in   = concat(src0[C0], src1[C1]) along channels, optional per-(b, channel) affine
 //          (GroupNorm folded to a*x+b) followed by optional SiLU, zero outside the image
 //   out  = ((conv(in) + conv1x1(x) + bias + temb[b]) + res) * out_scale + (w4 . pyr + b4)
-//   stats[b][tile][cout][2] = per-tile per-channel (sum, sum of squares) of the stored values
+//   stats[b][cout][2] += per-channel (sum, sum of squares) of this workgroup's stored values (fixed point, integer atomics)
 struct ConvArgs {
     const void* src0; const void* src1; int C0; int C1; int in_dtype;
     const float* coef;      // [B][C0+C1][2] (a, b) or null
+    // ... or the GroupNorm is finalised by the consumer itself (no separate launch): per-(item, channel) totals of the two
+    // concatenated sources as accumulated by their producers (see `stats`), the layer's affine and group count
+    const long long* gn_st0; const long long* gn_st1;       // [B][C0][2], [B][C1][2] fixed-point (sum, sum of squares); null: use coef
+    const float* gn_gamma; const float* gn_beta; int gn_groups; float gn_inv_n; float gn_eps;   // gn_inv_n = 1 / (channels per group * H * W)
     int act;                // 0: none, 1: SiLU (after the affine)
     const void* w;          // packed [CoutPad][ntaps][C0+C1] in in_dtype
     const void* wb;         // optional slab-major copy [ntaps][(C0+C1)/ck][CoutPad][ck], ck = conv_v4_chunk(in_dtype)
@@ -43,7 +47,8 @@ struct ConvArgs {
     const float* w4;        // [Cout][4]
     const float* b4;        // [Cout]
     void* out; int out_dtype;
-    float* stats;           // or null
+    long long* stats;       // or null: [B][Cout][2] fixed-point totals (sum * 2^20, sum of squares * 2^12) of the stored values,
+                            // accumulated with 64-bit integer atomics (order-independent, hence deterministic); zeroed by the caller
     int B, H, W, Cout, ntaps;
     int stagger, stagger_lo, stagger_hi;   // conv_v5_kernel: workgroups [lo, hi) of the dispatch order start `stagger` x s_sleep(127) late
     int dbg;                // ablation bits for kernel bring-up (0 in production)
@@ -75,15 +80,10 @@ inline bool conv_v6_eligible(const ConvArgs&) { return false; }
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 128 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);
-// number of per-image statistics tiles the kernel chosen for `a` writes (stats layout [B][tiles][Cout][2])
-inline int conv_out_tiles(const ConvArgs& a) {
-    return conv_v5_eligible(a) ? conv_v5_tiles(a.H, a.W) : conv_v4_eligible(a) ? conv_v4_tiles(a.H, a.W) : conv_v2_eligible(a) ? conv_v2_tiles(a.H, a.W) : tiles_per_image(a.H, a.W);
-}
-
-// GroupNorm finalisation: per-(b, group) mean / rstd from per-tile per-channel partial sums of up to
-// two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b):  y = a*x + b.
-void launch_gn_finalize(const float* st0, int C0, int ntiles0, const float* st1, int C1, int ntiles1, const float* gamma,
-                        const float* beta, int groups, int hw, float eps, float* coef, int B, hipStream_t s);
+// GroupNorm finalisation for the consumers that take a coefficient array (FIR resampling kernels): per-(b, group) mean / rstd
+// from the per-channel totals of up to two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b): y = a*x + b.
+void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta,
+                        int groups, int hw, float eps, float* coef, int B, hipStream_t s);
 
 // FIR x2 resampling with the separable [1,3,3,1] kernel (upfirdn2d semantics of the reference).
 // out_act (nullable) = FIR(act(a*x+b)), out_raw (nullable) = FIR(x).

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     char* const s_halo = smem;
     char* const s_w0 = smem + HALO_BYTES;
+    __shared__ float2 coef_s[1024];                          // GroupNorm affine of this item's input channels (gn_fill_table)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -79,6 +80,11 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (p.coef || p.gn_st0) {                                // GroupNorm finalised here (no separate launch), or copied
+        gn_fill_table(coef_s, p, b, Ctot, tid, 256);
+        __syncthreads();
+    }
 
     // per-lane fragment bases (bytes)
     int a_base[TM], b_base[TN];
@@ -103,14 +109,14 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
             if (c_glob < p.XC0) { src = (const TIN*)p.x0; Cs = p.XC0; c_loc = c_glob; }
             else                { src = (const TIN*)p.x1; Cs = p.XC1; c_loc = c_glob - p.XC0; }
         }
-        const bool use_coef = p.coef && !seg1;
+        const bool use_coef = (p.coef || p.gn_st0) && !seg1;
         const bool use_act = p.act && !seg1;
         const int part = tid % PARTS;                      // constant per thread (256 % PARTS == 0)
         float ca[VEC], cb[VEC];
         if (use_coef) {
-            const float* cf = p.coef + ((size_t)b * Ctot + c_glob + part * VEC) * 2;
+            const float2* cf = coef_s + c_glob + part * VEC;
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) { ca[k] = cf[2 * k]; cb[k] = cf[2 * k + 1]; }
+            for (int k = 0; k < VEC; ++k) { const float2 v = cf[k]; ca[k] = v.x; cb[k] = v.y; }
         }
         const int npix = HW_ * HH_;
         for (int idx = tid; idx < npix * PARTS; idx += 256) {
@@ -293,10 +299,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
 #pragma unroll
             for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
             const int co = n0 + tid;
-            if (co < p.Cout) {
-                float* dst = p.stats + (((size_t)b * gridDim.x + blockIdx.x) * p.Cout + co) * 2;
-                dst[0] = s; dst[1] = q;
-            }
+            if (co < p.Cout) gn_accumulate(p.stats + ((size_t)b * p.Cout + co) * 2, s, q);
         }
     }
 }
@@ -339,7 +342,13 @@ __global__ __launch_bounds__(256) void pyr_conv_kernel(ConvArgs p) {
         float ca[8], cb[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { ca[k] = 1.f; cb[k] = 0.f; }
-        if (p.coef) {
+        if (p.gn_st0) {                                      // GroupNorm finalised here: this thread's 8 channels of the block
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float2 v = gn_coef_of(p.gn_st0, p.C0, p.gn_st1, p.C1, p.gn_gamma, p.gn_beta, p.gn_groups, p.gn_inv_n, p.gn_eps, b, c0 + part * 8 + k);
+                ca[k] = v.x; cb[k] = v.y;
+            }
+        } else if (p.coef) {
             const float* cf = p.coef + ((size_t)b * Cin + c0 + part * 8) * 2;
 #pragma unroll
             for (int k = 0; k < 8; ++k) { ca[k] = cf[2 * k]; cb[k] = cf[2 * k + 1]; }
@@ -525,10 +534,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(ConvArgs p) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) { sm += s_red[(w * 128 + tid) * 2]; q += s_red[(w * 128 + tid) * 2 + 1]; }
             const int co = n0 + tid;
-            if (co < p.Cout) {
-                float* dst = p.stats + (((size_t)b * gridDim.x + blockIdx.x) * p.Cout + co) * 2;
-                dst[0] = sm; dst[1] = q;
-            }
+            if (co < p.Cout) gn_accumulate(p.stats + ((size_t)b * p.Cout + co) * 2, sm, q);
         }
     }
 }
@@ -602,52 +608,23 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// GroupNorm finalize: one block per (group, batch item)
+// GroupNorm finalize for the consumers that take a coefficient array (the FIR resampling kernels): one block per batch item
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ st0, int C0, int nt0,
-                                                          const float* __restrict__ st1, int C1, int nt1,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, int groups, int hw,
-                                                          float eps, float* __restrict__ coef) {
-    const int g = blockIdx.x, b = blockIdx.y;
-    const int C = C0 + C1, cpg = C / groups;
-    double s = 0.0, q = 0.0;
-    const int ntmax = nt0 > nt1 ? nt0 : nt1;                 // the two sources may come from kernels with different tilings
-    for (int idx = threadIdx.x; idx < ntmax * cpg; idx += 256) {
-        const int tile = idx / cpg, c = g * cpg + (idx - tile * cpg);
-        const float* p;
-        if (c < C0) { if (tile >= nt0) continue; p = st0 + (((size_t)b * nt0 + tile) * C0 + c) * 2; }
-        else        { if (tile >= nt1) continue; p = st1 + (((size_t)b * nt1 + tile) * C1 + (c - C0)) * 2; }
-        s += (double)p[0]; q += (double)p[1];
-    }
-    __shared__ double rs[4], rq[4];
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rq[threadIdx.x >> 6] = q; }
-    __syncthreads();
-    s = rs[0] + rs[1] + rs[2] + rs[3];
-    q = rq[0] + rq[1] + rq[2] + rq[3];
-    const double n = (double)cpg * (double)hw;
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    if (threadIdx.x < cpg) {
-        const int c = g * cpg + threadIdx.x;
-        const float a = gamma[c] * rstd;
-        coef[((size_t)b * C + c) * 2] = a;
-        coef[((size_t)b * C + c) * 2 + 1] = beta[c] - (float)mean * a;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const long long* __restrict__ st0, int C0, const long long* __restrict__ st1,
+                                                          int C1, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int groups, float inv_n, float eps, float* __restrict__ coef) {
+    const int b = blockIdx.x, C = C0 + C1;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float2 v = gn_coef_of(st0, C0, st1, C1, gamma, beta, groups, inv_n, eps, b, c);
+        coef[((size_t)b * C + c) * 2] = v.x;
+        coef[((size_t)b * C + c) * 2 + 1] = v.y;
     }
 }
 
-void launch_gn_finalize(const float* st0, int C0, int ntiles0, const float* st1, int C1, int ntiles1, const float* gamma,
-                        const float* beta, int groups, int hw, float eps, float* coef, int B, hipStream_t s) {
-    // timing experiment only: after the first $USE_HIP_SKIP_GNFIN launches the kernel is skipped (with a fixed plan and the
-    // same inputs the coefficients of the first evaluation stay valid, so the data - and the clocks - are unchanged)
-    static const long skip_after = getenv("USE_HIP_SKIP_GNFIN") ? atol(getenv("USE_HIP_SKIP_GNFIN")) : -1;
-    static long launches = 0;
-    if (skip_after >= 0 && launches++ >= skip_after) return;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, st0, C0, ntiles0, st1, C1, ntiles1, gamma, beta,
-                       groups, hw, eps, coef);
+void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta,
+                        int groups, int hw, float eps, float* coef, int B, hipStream_t s) {
+    const float inv_n = 1.0f / ((float)((C0 + C1) / groups) * (float)hw);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, st0, C0, st1, C1, gamma, beta, groups, inv_n, eps, coef);
 }
 
 // ---------------------------------------------------------------------------------------------------------
