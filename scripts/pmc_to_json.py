@@ -37,6 +37,11 @@ if "TCC_HIT_sum" in avg and "TCC_MISS_sum" in avg:
     res["l2_hit_rate"] = avg["TCC_HIT_sum"] / (avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])
 if "SQ_LDS_BANK_CONFLICT" in avg and "SQ_LDS_IDX_ACTIVE" in avg:
     res["lds_bank_conflict_frac_of_lds"] = avg["SQ_LDS_BANK_CONFLICT"] / avg["SQ_LDS_IDX_ACTIVE"]
+# provenance: bench.py quotes hbm_bytes_per_launch only while the kernel source is the one these counters were collected on
+import hashlib
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "universal_speech_enhancement_amd", "csrc", "use_conv_v4.hip")
+res["kernel_source"] = "universal_speech_enhancement_amd/csrc/use_conv_v4.hip"
+res["kernel_source_sha16"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16]
 res["raw_avg_per_dispatch"] = avg
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "raw_avg_per_dispatch"}, indent=1))

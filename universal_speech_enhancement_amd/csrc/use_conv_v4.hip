@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         const int hy = pix / V4_HW, hx = pix - hy * V4_HW;
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         const bool inb = idx < NPIECE && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        ppix[j] = inb ? (b * p.H + gy) * p.W + gx : 0;
+        ppix[j] = inb ? gy * p.W + gx : 0;                  // pixel offset inside the item's image (the item offset sits in the buffer base)
         pmask[j] = inb ? 0xffffffffu : 0u;
         pdst[j] = idx < NPIECE ? hy * HPITCH + hx * ROWB + part * 16 : -1;
     }
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         if (c_glob < p.C0) { src = (const TIN*)p.src0; Cs = p.C0; c_loc = c_glob; }
         else               { src = (const TIN*)p.src1; Cs = p.C1; c_loc = c_glob - p.C0; }
         const unsigned voff = (unsigned)pixoff * (unsigned)(Cs * (int)sizeof(TIN)) + (unsigned)(part * 16);
-        return buf_ld(src, voff, (unsigned)(c_loc * (int)sizeof(TIN)));
+        // per-item buffer base: the 32-bit offsets only have to span one image (any batch size, < 2 GB per image tensor)
+        return buf_ld(src + (size_t)b * p.H * p.W * Cs, voff, (unsigned)(c_loc * (int)sizeof(TIN)));
     };
     // ---- segment-1 (shortcut) pieces: the 16x32 centre pixels, 4 per thread, raw ----------------------------------------
     auto load_piece1 = [&](int chunk2, int q, uint4& raw) -> unsigned {
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         const TIN* src; int Cs, c_loc;
         if (c_glob < p.XC0) { src = (const TIN*)p.x0; Cs = p.XC0; c_loc = c_glob; }
         else                { src = (const TIN*)p.x1; Cs = p.XC1; c_loc = c_glob - p.XC0; }
-        const unsigned pixoff = inb ? (unsigned)((b * p.H + gy) * p.W + gx) : 0u;
-        raw = buf_ld(src, pixoff * (unsigned)(Cs * (int)sizeof(TIN)) + (unsigned)(part * 16), (unsigned)(c_loc * (int)sizeof(TIN)));
+        const unsigned pixoff = inb ? (unsigned)(gy * p.W + gx) : 0u;
+        raw = buf_ld(src + (size_t)b * p.H * p.W * Cs, pixoff * (unsigned)(Cs * (int)sizeof(TIN)) + (unsigned)(part * 16), (unsigned)(c_loc * (int)sizeof(TIN)));
         return inb ? 0xffffffffu : 0u;
     };
     auto piece1_dst = [&](int q, int hb) -> int {

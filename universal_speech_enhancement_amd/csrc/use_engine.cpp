@@ -120,6 +120,7 @@ struct use_handle {
     int B = 0, T = 0;
     Arena arena;
     char* persist = nullptr; size_t persist_bytes = 0;
+    size_t arena_alloc = 0, persist_alloc = 0;   // sizes of the two device allocations: kept at their high-water marks across re-plans
     float *x4 = nullptr, *silu_temb = nullptr, *tembias = nullptr, *t_dev = nullptr;
     float2 *Y = nullptr, *X = nullptr, *Xmean = nullptr, *score = nullptr, *xin = nullptr;
     float2 *cond_buf = nullptr;
@@ -955,8 +956,9 @@ int use_plan(use_handle* h, int B, int Tpad) {
     // sub-batch pipelining (run_score): `subbatch` sub-batches of at least 2 items each
     h->nsub = std::max(1, std::min(std::min(g_subbatch, MAX_SUB), B / 2));
     for (int i = 0; i < MAX_SUB; ++i) h->sub_B[i] = i < h->nsub ? B / h->nsub + (i < B % h->nsub ? 1 : 0) : 0;
-    // dry runs to size the activation arenas (one per sub-batch, carved from one allocation)
-    if (h->arena.base) { HIPCHK(hipFree(h->arena.base)); h->arena.base = nullptr; }
+    // dry runs to size the activation arenas (one per sub-batch, carved from one allocation).  The allocation itself is kept
+    // when it is large enough: a predict run over files of different lengths re-plans for almost every batch
+    char* old_base = h->arena.base;
     h->arena = Arena{};
     h->dry = true;
     size_t caps[MAX_SUB] = {0, 0, 0, 0}, stcaps[MAX_SUB] = {0, 0, 0, 0}, total = 0;
@@ -970,9 +972,13 @@ int use_plan(use_handle* h, int B, int Tpad) {
         stcaps[i] = (h->st_arena[i].peak + 255) & ~(size_t)255; total += stcaps[i];
     }
     h->dry = false;
-    char* base = nullptr;
-    if (hipMalloc((void**)&base, total) != hipSuccess)
-        return fail(USE_E_NOMEM, "cannot allocate %.1f MB of activation workspace", total / 1e6);
+    char* base = old_base;
+    if (!base || total > h->arena_alloc) {
+        if (base) { HIPCHK(hipFree(base)); base = nullptr; h->arena_alloc = 0; }
+        if (hipMalloc((void**)&base, total) != hipSuccess)
+            return fail(USE_E_NOMEM, "cannot allocate %.1f MB of activation workspace", total / 1e6);
+        h->arena_alloc = total;
+    }
     h->arena.base = base; h->arena.cap = total;               // owns the allocation (use_workspace_bytes reports cap)
     {
         size_t off = caps[0];
@@ -990,14 +996,17 @@ int use_plan(use_handle* h, int B, int Tpad) {
     // persistent buffers
     const size_t n = (size_t)B * h->cfg.n_freq * Tpad;
     h->lang_blocks = (int)std::min<size_t>(256, ((size_t)h->cfg.n_freq * Tpad + 255) / 256);
-    if (h->persist) { HIPCHK(hipFree(h->persist)); h->persist = nullptr; }
     size_t off = 0;
     auto take = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; size_t o = off; off += bytes; return o; };
     const size_t o_x4 = take(n * 16), o_Y = take(n * 8), o_X = take(n * 8), o_Xm = take(n * 8), o_sc = take(n * 8),
                  o_xin = take(n * 8), o_cond = take(n * 8), o_st = take((size_t)B * 4 * h->cfg.nf * 4), o_tb = take((size_t)B * h->dense_rows * 4),
                  o_t = take((size_t)B * 4), o_lp = take((size_t)B * h->lang_blocks * 2 * 4), o_ls = take(256), o_rng = take(256);
     h->persist_bytes = off;
-    if (hipMalloc((void**)&h->persist, off) != hipSuccess) return fail(USE_E_NOMEM, "cannot allocate %.1f MB of state", off / 1e6);
+    if (!h->persist || off > h->persist_alloc) {
+        if (h->persist) { HIPCHK(hipFree(h->persist)); h->persist = nullptr; h->persist_alloc = 0; }
+        if (hipMalloc((void**)&h->persist, off) != hipSuccess) return fail(USE_E_NOMEM, "cannot allocate %.1f MB of state", off / 1e6);
+        h->persist_alloc = off;
+    }
     h->x4 = (float*)(h->persist + o_x4); h->Y = (float2*)(h->persist + o_Y); h->X = (float2*)(h->persist + o_X);
     h->Xmean = (float2*)(h->persist + o_Xm); h->score = (float2*)(h->persist + o_sc); h->xin = (float2*)(h->persist + o_xin);
     h->cond_buf = (float2*)(h->persist + o_cond); h->Cond = h->Y;
