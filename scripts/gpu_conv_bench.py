@@ -28,6 +28,20 @@ CASES = {
     "L2 conv1 256->256 +res":   (128, 160, 256, 0, 256, 0, 0, 1, 1, 0, 1),
     "L2 conv0 cat512->256":     (128, 160, 256, 256, 256, 0, 0, 1, 1, 1, 0),
     "L3 conv0 256->256":        (64, 80, 256, 0, 256, 0, 0, 1, 1, 1, 0),
+    "L3 conv0 cat512->256":     (64, 80, 256, 256, 256, 0, 0, 1, 1, 1, 0),
+    "L4 conv0 256->256":        (32, 40, 256, 0, 256, 0, 0, 1, 1, 1, 0),
+    "L4 conv1 256->256 +res":   (32, 40, 256, 0, 256, 0, 0, 1, 1, 0, 1),
+    "L4 conv0 cat512->256":     (32, 40, 256, 256, 256, 0, 0, 1, 1, 1, 0),
+    "L4 conv1 256->256 +sc512": (32, 40, 256, 0, 256, 256, 256, 1, 1, 0, 0),
+    "L5 conv0 256->256":        (16, 20, 256, 0, 256, 0, 0, 1, 1, 1, 0),
+    "L5 conv0 cat512->256":     (16, 20, 256, 256, 256, 0, 0, 1, 1, 1, 0),
+    "L5 conv1 256->256 +sc512": (16, 20, 256, 0, 256, 256, 256, 1, 1, 0, 0),
+    "L6 conv0 256->256":        (8, 10, 256, 0, 256, 0, 0, 1, 1, 1, 0),
+    "L6 conv1 256->256 +res":   (8, 10, 256, 0, 256, 0, 0, 1, 1, 0, 1),
+    "L6 conv0 cat512->256":     (8, 10, 256, 256, 256, 0, 0, 1, 1, 1, 0),
+    "L6 conv0 noact nogn":      (8, 10, 256, 0, 256, 0, 0, 0, 0, 1, 0),
+    "odd 7x9 96->96 +sc192":    (7, 9, 96, 0, 96, 96, 96, 1, 1, 0, 0),
+    "odd 5x33 cat160->64":      (5, 33, 96, 64, 64, 0, 0, 1, 1, 1, 0),
 }
 MAIN = ["L0 conv0 128->128", "L0 conv1 128->128 +res", "L0 conv1 128->128 +sc256", "L1 conv0 cat384->128", "L2 conv0 256->256"]
 
@@ -60,7 +74,8 @@ def main():
         k, v = o.split("=")
         check(_lib.lib().use_set_option(k.encode(), int(v)), "use_set_option")
     variants = [int(v) for v in a.variants.split(",")]
-    names = MAIN if a.cases == "main" else list(CASES) if a.cases == "all" else [n for n in CASES if a.cases in n]
+    names = (MAIN if a.cases == "main" else list(CASES) if a.cases == "all" else
+             [n for n in CASES if any(k in n for k in a.cases.split(","))])
     for name in names:
         case = CASES[name]
         ref = None

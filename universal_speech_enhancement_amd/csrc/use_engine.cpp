@@ -752,6 +752,7 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
     if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
+    if (!strcmp(name, "conv_sk_max_px")) { conv_sk_set_max_px((long)value); return USE_OK; }             // 0: conv_sk off
 #ifdef USE_HIP_EXPERIMENTS
     if (!strcmp(name, "conv_v5_min_blocks")) { conv_v5_set_min_blocks((long)value); return USE_OK; }
     if (!strcmp(name, "conv_v5_stagger")) { conv_v5_set_stagger((int)value); return USE_OK; }
@@ -1378,6 +1379,8 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
     auto run = [&]() -> int {
         switch (c->variant) {
             case 0: launch_conv(a, 0); return 0;
+            case 1: launch_conv_generic(a, 0); return 0;
+            case 7: if (!conv_sk_eligible(a)) return -1; launch_conv_sk(a, 0); return 0;
             case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
             case 4: if (!a.wb || (XC && !a.w2b)) return -1; launch_conv_v4(a, 0); return 0;
 #ifdef USE_HIP_EXPERIMENTS

@@ -77,6 +77,11 @@ void launch_conv_v6(const ConvArgs& a, hipStream_t s);
 inline bool conv_v5_eligible(const ConvArgs&) { return false; }
 inline bool conv_v6_eligible(const ConvArgs&) { return false; }
 #endif
+// split-K variant for the small maps (use_conv_sk.hip): 64-pixel x 32/64-channel tiles, the 8 waves of a workgroup split K
+bool conv_sk_eligible(const ConvArgs& a);
+void conv_sk_set_max_px(long n);                         // largest map (H*W) it is used for (default 16x20)
+void launch_conv_sk(const ConvArgs& a, hipStream_t s);
+void launch_conv_generic(const ConvArgs& a, hipStream_t s);   // conv_kernel / pyr_conv_kernel / conv_in_kernel only (no specialised schedule)
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 128 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);

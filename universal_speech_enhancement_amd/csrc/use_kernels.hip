@@ -21,6 +21,7 @@
 #include "use_kernels.h"
 #include <type_traits>
 #include <cstdlib>
+#include <cstdio>
 #include "use_device.h"
 
 #include <math.h>
@@ -550,12 +551,24 @@ static void conv_launch_t(const ConvArgs& a, hipStream_t s) {
 }
 
 void launch_conv(const ConvArgs& a, hipStream_t s) {
+#ifdef USE_HIP_SKIPDBG   // timing-only bring-up build: drop the convolutions of maps with lo <= H*W <= hi pixels (USE_HIP_SKIP="lo:hi")
+    {
+        static long lo = -1, hi = -1;
+        if (lo < 0) { lo = 0; hi = -1; if (const char* e = getenv("USE_HIP_SKIP")) sscanf(e, "%ld:%ld", &lo, &hi); }
+        if ((long)a.H * a.W >= lo && (long)a.H * a.W <= hi) return;
+    }
+#endif
 #ifdef USE_HIP_EXPERIMENTS
     if (conv_v5_eligible(a)) { launch_conv_v5(a, s); return; }
     if (conv_v6_eligible(a)) { launch_conv_v6(a, s); return; }
 #endif
+    if (conv_sk_eligible(a) && !pyr_conv_eligible(a)) { launch_conv_sk(a, s); return; }
     if (conv_v4_eligible(a)) { launch_conv_v4(a, s); return; }
     if (conv_v2_eligible(a)) { launch_conv_v2(a, s); return; }
+    launch_conv_generic(a, s);
+}
+
+void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
     if (pyr_conv_eligible(a)) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -883,9 +896,17 @@ static void fir_launch(const void* src, int dtype, const float* coef, int act, v
     }
 }
 void launch_fir_up2(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
-                    int H, int W, int C, hipStream_t s) { fir_launch<true>(src, dtype, coef, act, out_act, out_raw, B, H, W, C, s); }
+                    int H, int W, int C, hipStream_t s) {
+#ifdef USE_HIP_SKIPDBG
+    if (getenv("USE_HIP_SKIP_FIR")) return;
+#endif
+    fir_launch<true>(src, dtype, coef, act, out_act, out_raw, B, H, W, C, s); }
 void launch_fir_down2(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
-                      int H, int W, int C, hipStream_t s) { fir_launch<false>(src, dtype, coef, act, out_act, out_raw, B, H, W, C, s); }
+                      int H, int W, int C, hipStream_t s) {
+#ifdef USE_HIP_SKIPDBG
+    if (getenv("USE_HIP_SKIP_FIR")) return;
+#endif
+    fir_launch<false>(src, dtype, coef, act, out_act, out_raw, B, H, W, C, s); }
 
 static int ew_blocks(long n) { long b = (n + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
 // ---------------------------------------------------------------------------------------------------------
