@@ -155,16 +155,16 @@ DEVI void gn_fill_table(float2* tab, const ARGS& p, int b, int Ctot, int tid, in
                  : p.coef ? *reinterpret_cast<const float2*>(p.coef + ((size_t)b * Ctot + c) * 2) : make_float2(1.f, 0.f);
 }
 
-// Sum over the lanes {l, l+S, l+2S, ...} of a wave (S = 4, 8 or 16) with VALU cross-lane ops only (DPP row rotate,
+// Sum over the lanes {l, l+S, l+2S, ...} of a wave (S = 4, 8, 16 or 32) with VALU cross-lane ops only (DPP row rotate,
 // v_permlane16_swap, v_permlane32_swap) -- no LDS round trips (ds_bpermute) on the epilogue's critical path.
 template <int S>
 DEVI float reduce_lanes_stride(float v) {
-    static_assert(S == 4 || S == 8 || S == 16, "stride");
+    static_assert(S == 4 || S == 8 || S == 16 || S == 32, "stride");
     if (S <= 4)   // lanes i, i+4, i+8, i+12 of each 16-lane row: rotate by 4, then by 8 (sums are rotation-invariant)
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
     if (S <= 8)   // row_ror:8
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
-    {             // xor 16: after the swap the two results hold (row0,row0,row2,row2) and (row1,row1,row3,row3)
+    if (S <= 16) {   // xor 16: after the swap the two results hold (row0,row0,row2,row2) and (row1,row1,row3,row3)
         const int vi = __builtin_bit_cast(int, v);
         const auto r = __builtin_amdgcn_permlane16_swap(vi, vi, false, false);
         v = __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);

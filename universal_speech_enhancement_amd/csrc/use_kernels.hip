@@ -430,25 +430,30 @@ static bool pyr_conv_eligible(const ConvArgs& a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // conv_in_kernel: the network's first convolution (4 fp32 input channels -> Cout, 3x3, reference ncsnpp.py:326-331).
-// K = 36 is too shallow for the MFMA pipeline of conv_kernel (nine 4-deep chunks, a barrier each); the layer is bound by
-// writing its output, so it is a direct fp32 convolution on the VALU: one workgroup per 8x16-pixel tile x 128 output
-// channels, thread = (8-channel group, pixel column) x 8 rows, weights of one tap at a time in registers.
-// Output rounding, per-tile GroupNorm statistics and their layout are those of conv_kernel.
+// K = 36 is too shallow for conv_kernel's chunked pipeline (nine 4-deep chunks, a barrier each) and a direct fp32 convolution
+// on the VALU is bound by its 6 GFMA per launch (175 us at 512x640, measured 298); the layer should be bound by writing its
+// output.  So: fp32 MFMA (v_mfma_f32_32x32x2_f32, the input stays fp32 in every precision mode), one workgroup per 8x16-pixel
+// tile x 128 output channels, the 10x18x4 halo and the 128x36 weights staged in LDS once, then each wave runs its 32 pixels x
+// 128 channels as 4 x 18 MFMAs with no barrier, and the tile leaves through an LDS transpose as 16-byte stores (256 contiguous
+// bytes per pixel).  Output rounding, GroupNorm statistics of the stored values and their layout are those of conv_kernel.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int CIN_WP = 37;                                   // weight row pitch (floats): odd -> conflict-free over output channels
+constexpr int CIN_SP = 136;                                  // staging row pitch (floats) of a 32-pixel x 128-channel wave tile
 template <typename TOUT>
 __global__ __launch_bounds__(256) void conv_in_kernel(ConvArgs p) {
-    constexpr int CH = 8;                                    // output channels per thread
-    __shared__ __attribute__((aligned(16))) float s_in[(TILE_H + 2) * (TILE_W + 2) * 4];
-    __shared__ __attribute__((aligned(16))) float s_w[9 * 4 * 128];          // [tap][ci][co]
+    constexpr int HALO = (TILE_H + 2) * (TILE_W + 2);
+    constexpr int MAIN_BYTES = (HALO * 4 + 128 * CIN_WP) * 4, STG_BYTES = 4 * 32 * CIN_SP * 4;
+    __shared__ __attribute__((aligned(16))) char smem[MAIN_BYTES > STG_BYTES ? MAIN_BYTES : STG_BYTES];
     __shared__ float s_red[4 * 128 * 2];
+    float* const s_in = reinterpret_cast<float*>(smem);      // [10 x 18][4]
+    float* const s_w = s_in + HALO * 4;                      // [128 co][36 (+1)]: k = tap * 4 + ci
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cg = tid & 15, pl = tid >> 4;                  // channel group, pixel column
     const int b = blockIdx.z;
     const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
     const int ty0 = (blockIdx.x / tiles_x) * TILE_H, tx0 = (blockIdx.x % tiles_x) * TILE_W;
     const int n0 = blockIdx.y * 128;
     const float* src = (const float*)p.src0;
-    for (int i = tid; i < (TILE_H + 2) * (TILE_W + 2); i += 256) {
+    for (int i = tid; i < HALO; i += 256) {
         const int hy = i / (TILE_W + 2), hx = i - hy * (TILE_W + 2);
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -460,74 +465,72 @@ __global__ __launch_bounds__(256) void conv_in_kernel(ConvArgs p) {
         const int co = i / 9, tap = i - co * 9;
         const float4 w4 = n0 + co < p.cout_pad ? *reinterpret_cast<const float4*>(wsrc + ((size_t)(n0 + co) * 9 + tap) * 4)
                                                : make_float4(0.f, 0.f, 0.f, 0.f);
-        s_w[(tap * 4 + 0) * 128 + co] = w4.x; s_w[(tap * 4 + 1) * 128 + co] = w4.y;
-        s_w[(tap * 4 + 2) * 128 + co] = w4.z; s_w[(tap * 4 + 3) * 128 + co] = w4.w;
+        float* d = s_w + co * CIN_WP + tap * 4;
+        d[0] = w4.x; d[1] = w4.y; d[2] = w4.z; d[3] = w4.w;
     }
     __syncthreads();
-    float acc[TILE_H][CH];
+    // wave w: tile rows 2w, 2w+1 (32 pixels) x 128 channels.  MFMA k-step s: k = 2s + (lane >> 5) -> tap = s >> 1, ci = 2 (s & 1) + (lane >> 5)
+    f32x16 acc[4];
 #pragma unroll
-    for (int r = 0; r < TILE_H; ++r)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int c = 0; c < CH; ++c) acc[r][c] = 0.f;
-#pragma unroll 1                                             // one tap's 32 weights in registers at a time
-    for (int tap = 0; tap < 9; ++tap) {
-        float w[4][CH];
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int m = lane & 31;
+    const float* const pa = s_in + ((wave * 2 + (m >> 4)) * (TILE_W + 2) + (m & 15)) * 4 + (lane >> 5);
+    const float* const pb = s_w + m * CIN_WP + (lane >> 5);
 #pragma unroll
-        for (int ci = 0; ci < 4; ++ci) {
-            const float4 a = *reinterpret_cast<const float4*>(s_w + (tap * 4 + ci) * 128 + cg * CH);
-            const float4 c4 = *reinterpret_cast<const float4*>(s_w + (tap * 4 + ci) * 128 + cg * CH + 4);
-            w[ci][0] = a.x; w[ci][1] = a.y; w[ci][2] = a.z; w[ci][3] = a.w;
-            w[ci][4] = c4.x; w[ci][5] = c4.y; w[ci][6] = c4.z; w[ci][7] = c4.w;
-        }
-        const int dy = tap / 3, dx = tap % 3;
+    for (int s = 0; s < 18; ++s) {
+        const int tap = s >> 1, dy = tap / 3, dx = tap % 3;
+        const float a = pa[(dy * (TILE_W + 2) + dx) * 4 + 2 * (s & 1)];
 #pragma unroll
-        for (int r = 0; r < TILE_H; ++r) {
-            const float4 x = *reinterpret_cast<const float4*>(s_in + ((r + dy) * (TILE_W + 2) + pl + dx) * 4);
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[j * 32 * CIN_WP + 2 * s], acc[j], 0, 0, 0);
+    }
+    __syncthreads();                                         // every wave is done with the operands: the region becomes the staging
+    float* const stg = reinterpret_cast<float*>(smem) + wave * (32 * CIN_SP);
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
-                acc[r][c] = fmaf(x.x, w[0][c], fmaf(x.y, w[1][c], fmaf(x.z, w[2][c], fmaf(x.w, w[3][c], acc[r][c]))));
+    for (int j = 0; j < 4; ++j) {
+        const int co = n0 + j * 32 + m;
+        const float add = (co < p.Cout && p.bias) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            stg[row * CIN_SP + j * 32 + m] = (acc[j][r] + add) * p.out_scale;
         }
     }
-    const int co0 = n0 + cg * CH;
-    const bool cok = co0 < p.Cout;
-    float bias[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) bias[c] = (cok && p.bias) ? p.bias[co0 + c] : 0.f;
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CH = 16 / (int)sizeof(TOUT);               // output channels per 16-byte chunk
+    constexpr int CPR = 128 / CH;                            // chunks per pixel: 16 or 32
+    constexpr int PPQ = 64 / CPR;                            // pixels per pass of the wave
+    const int ch = lane % CPR, co0 = n0 + ch * CH;
+    const bool cok = co0 < p.Cout;                           // Cout is a multiple of 8
     float st_s[CH], st_q[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) { st_s[c] = 0.f; st_q[c] = 0.f; }
     TOUT* out = (TOUT*)p.out;
-    const int gx = tx0 + pl;
 #pragma unroll
-    for (int r = 0; r < TILE_H; ++r) {
-        const int gy = ty0 + r;
+    for (int q = 0; q < 32 / PPQ; ++q) {
+        const int row = q * PPQ + lane / CPR;
+        const int gy = ty0 + wave * 2 + (row >> 4), gx = tx0 + (row & 15);
         if (!cok || gy >= p.H || gx >= p.W) continue;
         float v[CH];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) v[c] = (acc[r][c] + bias[c]) * p.out_scale;
-        TOUT* dst = out + ((size_t)(b * p.H + gy) * p.W + gx) * p.Cout + co0;
-        float vr[CH];
-        if (sizeof(TOUT) == 2) {
-            typedef typename std::conditional<sizeof(TOUT) == 2, TOUT, __bf16>::type T16;   // (the fp32 instantiation never gets here)
-            const uint4 packed = Vec16<T16>::pack(v);
-            *reinterpret_cast<uint4*>(dst) = packed;
-            Vec16<T16>::load(reinterpret_cast<const T16*>(&packed), vr);
-        } else {
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + 4) = make_float4(v[4], v[5], v[6], v[7]);
-#pragma unroll
-            for (int c = 0; c < CH; ++c) vr[c] = v[c];
+        for (int c4 = 0; c4 < CH / 4; ++c4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(stg + row * CIN_SP + ch * CH + c4 * 4);
+            v[c4 * 4] = t4.x; v[c4 * 4 + 1] = t4.y; v[c4 * 4 + 2] = t4.z; v[c4 * 4 + 3] = t4.w;
         }
+        const uint4 packed = Vec16<TOUT>::pack(v);
+        *reinterpret_cast<uint4*>(out + ((size_t)(b * p.H + gy) * p.W + gx) * p.Cout + co0) = packed;
+        float vr[CH];
+        Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&packed), vr);       // statistics of the stored values
 #pragma unroll
         for (int c = 0; c < CH; ++c) { st_s[c] += vr[c]; st_q[c] += vr[c] * vr[c]; }
     }
     if (p.stats) {
-        // lanes of a wave that hold the same channel group are 16 apart (4 pixel columns per wave)
 #pragma unroll
-        for (int c = 0; c < CH; ++c) { st_s[c] = reduce_lanes_stride<16>(st_s[c]); st_q[c] = reduce_lanes_stride<16>(st_q[c]); }
-        if (lane < 16) {
+        for (int c = 0; c < CH; ++c) { st_s[c] = reduce_lanes_stride<CPR>(st_s[c]); st_q[c] = reduce_lanes_stride<CPR>(st_q[c]); }
+        if (lane < CPR) {
 #pragma unroll
-            for (int c = 0; c < CH; ++c) { s_red[(wave * 128 + cg * CH + c) * 2] = st_s[c]; s_red[(wave * 128 + cg * CH + c) * 2 + 1] = st_q[c]; }
+            for (int c = 0; c < CH; ++c) { s_red[(wave * 128 + ch * CH + c) * 2] = st_s[c]; s_red[(wave * 128 + ch * CH + c) * 2 + 1] = st_q[c]; }
         }
         __syncthreads();
         if (tid < 128) {
