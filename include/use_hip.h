@@ -163,6 +163,20 @@ typedef struct use_conv_case {
     int variant, iters;
 } use_conv_case;
 int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, double* ms_avg, double* flops);
+/* ---- wire formats either side of the path, host functions: no device, no handle ----
+ * use_wav_read: RIFF/WAVE (PCM 8/16/24/32-bit, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE) -> interleaved float64 frames scaled like
+ *   libsndfile's sf.read (integer PCM / 2^(bits-1)); *samples is malloc'ed, release it with use_free.
+ * use_resample_fft: scipy.signal.resample(x, num) == librosa.resample(res_type="fft") for real x (loadwav_dataset.py:95-98).
+ * use_load_utterance: the reference's inference loader for one file (loadwav_dataset.py:90-120): first channel, FFT resampling
+ *   to target_rate (0: keep), x / max|x| * 0.8 when normalize, float64 throughout, float32 out (malloc'ed; use_free).
+ * use_wav_write: sf.write(path, x, rate) of SGMSE_module.py:80 (USE_WAV_PCM16 = soundfile's default WAV subtype) or 32-bit float. */
+enum { USE_WAV_PCM16 = 0, USE_WAV_FLOAT32 = 1 };
+int use_wav_read(const char* path, double** samples, int64_t* frames, int* channels, int* sample_rate);
+int use_wav_write(const char* path, const float* samples, int64_t frames, int channels, int sample_rate, int subtype);
+int use_resample_fft(const double* x, int64_t n, int64_t num, double* y);
+int use_load_utterance(const char* path, int target_rate, int normalize, float** wav, int64_t* length, int* sample_rate);
+void use_free(void* p);
+
 /* timesteps of the sampler, torch.linspace(1, t_eps, N) float32 semantics (sampling/__init__.py:63); host only */
 int use_timesteps(int N, float t_eps, float* out);
 int use_debug_tensor(use_handle* h, const char* name, void** dev_ptr, int* dims4, int* dtype);

@@ -409,8 +409,15 @@ def test_predict_step_writes_trimmed_wavs(tmp_path, sd_np):
     out = mod.predict_step(batch, 0)
     assert out["enhanced"].shape == (2, 8000)
     sr, a = wavfile.read(f"{dst}/x/a.wav"); _, b = wavfile.read(f"{dst}/b.wav")
-    assert sr == 24000 and a.shape == (8000,) and b.shape == (5000,) and a.dtype == np.float32
-    np.testing.assert_allclose(b, out["enhanced"][1, :5000].cpu().numpy(), atol=1e-6)
+    # the reference's sf.write default: 16-bit PCM, round(x * 32767)
+    assert sr == 24000 and a.shape == (8000,) and b.shape == (5000,) and a.dtype == np.int16
+    want = np.clip(np.rint(out["enhanced"][1, :5000].cpu().numpy().astype(np.float64) * 32767.0), -32768, 32767)
+    np.testing.assert_array_equal(b.astype(np.float64), want)
+    mod.wav_subtype = "FLOAT"
+    out = mod.predict_step(batch, 0)
+    _, b = wavfile.read(f"{dst}/b.wav")
+    assert b.dtype == np.float32
+    np.testing.assert_array_equal(b, out["enhanced"][1, :5000].cpu().numpy())
 
 
 def test_weight_blob_broadcast_equivalence(engines, sd_np):
@@ -569,7 +576,8 @@ def test_predict_cli_from_lightning_checkpoint(tmp_path, sd_np):
     assert P.predict(P.compose(common + [f"ckpt_path={packed}", f"data.target_folder={dst2}"])) == 2
     _, a2 = wavfile.read(str(dst2 / "a.wav"))
     # device Philox noise with the default seed on both runs: same weights -> same samples
-    np.testing.assert_allclose(a2, a, rtol=0, atol=1e-6)
+    assert a.dtype == np.int16
+    np.testing.assert_allclose(a2.astype(np.int32), a.astype(np.int32), rtol=0, atol=1)
 
 
 def test_device_stft_istft_match_torch():

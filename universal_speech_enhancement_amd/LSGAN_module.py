@@ -17,9 +17,10 @@ from .SGMSE_module import _write_wav
 class GANModule(torch.nn.Module):
     def __init__(self, G: torch.nn.Module, D=None, G_optimizer=None, D_optimizer=None, G_scheduler=None, D_scheduler=None,
                  G_criterion=None, D_criterion=None, compile: bool = False, accumulate_grad_batches: int = 1,
-                 rewrite_lr=False, G_lr=None, D_lr=None):
+                 rewrite_lr=False, G_lr=None, D_lr=None, wav_subtype: str = "PCM_16"):
         super().__init__()
         self.G = G
+        self.wav_subtype = wav_subtype
         self.compile = compile
 
     def load_lightning_checkpoint(self, path: str, map_location="cpu"):
@@ -42,7 +43,7 @@ class GANModule(torch.nn.Module):
             sample_rate = batch["sampling_rate"][i]
             enhanced_path = noisy_path.replace(batch["data_folder"], batch["target_folder"])
             os.makedirs(os.path.dirname(enhanced_path) or ".", exist_ok=True)
-            _write_wav(enhanced_path, fake.detach().cpu().numpy().astype(np.float32)[:sample_length], sample_rate)
+            _write_wav(enhanced_path, fake.detach().cpu().numpy().astype(np.float32)[:sample_length], sample_rate, self.wav_subtype)
         return batch
 
     def training_step(self, *a, **k):

@@ -11,19 +11,21 @@ import numpy as np
 import torch
 
 
-def _write_wav(path: str, wav: np.ndarray, sr: int):
-    try:
-        import soundfile as sf  # the reference's writer (SGMSE_module.py:80)
-        sf.write(path, wav, sr)
-    except ImportError:
-        from scipy.io import wavfile
-        wavfile.write(path, int(sr), wav.astype(np.float32))
+def _write_wav(path: str, wav: np.ndarray, sr: int, subtype: str = "PCM_16"):
+    """``sf.write(path, wav, sr)`` of the reference (SGMSE_module.py:80): soundfile's default WAV subtype is 16-bit PCM;
+    ``subtype="FLOAT"`` keeps the float32 samples.  Native writer (csrc/use_io.cpp: use_wav_write)."""
+    from .wavio import FLOAT32, PCM16, write_wav
+    if subtype not in ("PCM_16", "FLOAT"):
+        raise ValueError(f"unsupported WAV subtype {subtype!r} (PCM_16 or FLOAT)")
+    write_wav(path, wav, int(sr), PCM16 if subtype == "PCM_16" else FLOAT32)
 
 
 class SGMSEModule(torch.nn.Module):
-    def __init__(self, Score: torch.nn.Module, optimizer=None, scheduler=None, compile: bool = False, sampler_kwargs=None):
+    def __init__(self, Score: torch.nn.Module, optimizer=None, scheduler=None, compile: bool = False, sampler_kwargs=None,
+                 wav_subtype: str = "PCM_16"):
         super().__init__()
         self.Score = Score
+        self.wav_subtype = wav_subtype                       # "PCM_16" = what the reference's sf.write produces; "FLOAT" = float32
         self.optimizer, self.scheduler, self.compile = optimizer, scheduler, compile
         self.sampler_kwargs = dict(sampler_kwargs or {})     # optional N / corrector_steps / snr overrides
 
@@ -48,7 +50,7 @@ class SGMSEModule(torch.nn.Module):
             enhanced_path = noisy_path.replace(batch["data_folder"], batch["target_folder"])
             os.makedirs(os.path.dirname(enhanced_path) or ".", exist_ok=True)
             wav = enhanced.detach().cpu().numpy().astype(np.float32)[:sample_length]
-            _write_wav(enhanced_path, wav, sample_rate)
+            _write_wav(enhanced_path, wav, sample_rate, self.wav_subtype)
         return batch
 
     def training_step(self, *a, **k):

@@ -77,6 +77,11 @@ SYMBOLS = {
     "use_profile_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double)]),
     "use_timesteps": (_i, [_i, _f, C.POINTER(_f)]),
     "use_conv_bench": (_i, [C.POINTER(UseConvCase), _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "use_wav_read": (_i, [C.c_char_p, C.POINTER(C.POINTER(C.c_double)), C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),
+    "use_wav_write": (_i, [C.c_char_p, _vp, _i64, _i, _i, _i]),
+    "use_resample_fft": (_i, [_vp, _i64, _i64, _vp]),
+    "use_load_utterance": (_i, [C.c_char_p, _i, _i, C.POINTER(C.POINTER(C.c_float)), C.POINTER(_i64), C.POINTER(_i)]),
+    "use_free": (None, [_vp]),
 }
 
 

@@ -30,6 +30,8 @@ static int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+// error reporting for the other translation units of the library (use_io.cpp)
+int use_set_error(int code, const char* msg) { g_err = msg ? msg : ""; return code; }
 #define HIPCHK(expr)                                                                                         \
     do {                                                                                                     \
         hipError_t e_ = (expr);                                                                              \

@@ -12,28 +12,7 @@ import numpy as np
 import torch
 
 from .distributed import shard_list
-
-
-def _read_wav(path: str):
-    try:
-        import soundfile as sf
-        data, sr = sf.read(path)
-        return np.asarray(data, dtype=np.float64), int(sr)
-    except ImportError:
-        from scipy.io import wavfile
-        sr, data = wavfile.read(path)
-        if data.dtype.kind == "i":
-            data = data.astype(np.float64) / float(np.iinfo(data.dtype).max + 1)
-        elif data.dtype.kind == "u":
-            data = (data.astype(np.float64) - 128.0) / 128.0
-        return data.astype(np.float64), int(sr)
-
-
-def _resample_fft(x: np.ndarray, sr: int, target: int) -> np.ndarray:
-    if sr == target:
-        return x
-    from scipy.signal import resample          # FFT resampling, as librosa's res_type="fft"
-    return resample(x, int(np.ceil(len(x) * target / sr)))
+from .wavio import load_utterance
 
 
 class LoadWavData:
@@ -50,15 +29,8 @@ class LoadWavData:
         return len(self.filepaths)
 
     def _item(self, path: str) -> Dict:
-        x, sr = _read_wav(path)
-        if x.ndim == 2:
-            x = x[:, 0]
-        if self.sampling_rate:
-            x = _resample_fft(x, sr, self.sampling_rate)
-        if self.normalize:
-            x = x / np.max(np.abs(x)) * 0.8
-        return {"perturbed": x.astype(np.float32), "name": os.path.basename(path).split(".wav")[0], "audio_path": path,
-                "sampling_rate": self.sampling_rate or sr}
+        x, sr = load_utterance(path, self.sampling_rate, self.normalize)       # native loader (csrc/use_io.cpp)
+        return {"perturbed": x, "name": os.path.basename(path).split(".wav")[0], "audio_path": path, "sampling_rate": sr}
 
     def predict_batches(self, device="cuda") -> Iterator[Dict]:
         for i in range(0, len(self.filepaths), self.batch_size):
