@@ -47,7 +47,7 @@ typedef struct use_config {
     float theta, sigma_min, sigma_max; /* OUVE SDE (1.5, 0.05, 0.5)              sdes.py:184             */
     /* NCSNpp(discriminative=True), the generator of the LSGAN refine stage (ncsnpp.py:86-92,
      * GAN/generator/ncsnpp/model_wrapper.py:54): 0 everywhere = the score network above */
-    int input_channels;    /* real input channels: 0 or 4 = (x.re, x.im, y.re, y.im); 2 = (y.re, y.im)  ncsnpp.py:63,92 */
+    int input_channels;    /* real input channels: 0 or 4 = (x, y) re/im; 2 = (y) alone; 6 = (x, y, y2)   ncsnpp.py:63,92 */
     int unconditional;     /* 1: no time embedding (conditional=False)                                 ncsnpp.py:89   */
     int no_sigma_scale;    /* 1: output not divided by t (scale_by_sigma=False)                        ncsnpp.py:90   */
 } use_config;
@@ -98,6 +98,9 @@ int use_workspace_bytes(use_handle* h, size_t* bytes);
 
 /* One score evaluation: out = -score_net(cat[x, y], t).  x, y, out: complex64 [B,1,F,T']; t: float32 [B] (device). */
 int use_score(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream);
+/* The same for a handle created with input_channels = 6 (ScoreModel(condition="both"), model_wrapper.py:43-46, 287-288):
+ * out = -score_net(cat[x, y, y2], t) with the two conditioning spectrograms [Y, Y_denoised]. */
+int use_score2(use_handle* h, const void* x, const void* y, const void* y2, const float* t, void* out, use_stream_t stream);
 
 /* Whole PC sampler: prior sampling -> N x (corrector, predictor) -> x_mean of the last predictor step.
  * noise: complex64 [n_draws][B,1,F,T'] consumed in the reference's order (prior, then per step the corrector
@@ -110,6 +113,9 @@ int use_sample(use_handle* h, const void* y, const void* noise, uint64_t seed, v
  * prior mean and the result refer to y -- ScoreModel.sample with condition="denoised" (conditioning = the GAN-denoised
  * spectrogram) and sde_input "noisy" or "denoised" (model_wrapper.py:283-301).  cond == NULL is use_sample. */
 int use_sample_cond(use_handle* h, const void* y, const void* cond, const void* noise, uint64_t seed, void* out, use_stream_t stream);
+/* condition="both": the network sees cat[x, cond, cond2] (6-channel handle; cond == NULL: the SDE's y). */
+int use_sample_cond2(use_handle* h, const void* y, const void* cond, const void* cond2, const void* noise, uint64_t seed, void* out,
+                     use_stream_t stream);
 
 /* Element-wise SDE pieces for callers that drive the loop themselves through the reference's
  * Predictor / Corrector registries (uniform t over the batch). n = number of complex elements. */

@@ -260,6 +260,39 @@ def gen_sample_denoised(model=None):
              weights_crc=crc)
 
 
+def gen_both(model=None):
+    """condition="both" (the reference's constructor default, model_wrapper.py:43-46, 287-288): the 6-channel network
+    NCSNppLarge(input_channels=6) sees cat[x, Y, Y_denoised].  One forward at [2,3,512,64] and ScoreModel.sample for both choices
+    of sde_input (0.4 s utterance, N=3, langevin x1)."""
+    sd = tw.make_state_dict(1234, **tw.LARGE_BOTH)
+    crc = tw.weights_checksum(sd)
+    x = torch.from_numpy(tnoise.complex_normal(17, "both_x", (2, 3, 512, 64))) * 0.5
+    t = torch.tensor([0.7, 0.05], dtype=torch.float32)
+    wav = torch.from_numpy(tnoise.synth_noisy_speech(1, 9600, seed=77))
+    fake = torch.from_numpy(tnoise.synth_noisy_speech(1, 9600, seed=78)) * 0.7 + 0.3 * wav
+    draws = tnoise.sampler_noise(4321, 1 + 3 * 2, (1, 1, 512, 64))
+    out = {}
+    for sde_input in ("noisy", "denoised"):
+        torch.manual_seed(0)
+        m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition="both", n_fft=1022, hop_length=160,
+                       num_frames=512, window="hann", sde_input=sde_input, predictor="reverse_diffusion", corrector="langevin").eval()
+        m.score_net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        if sde_input == "noisy":
+            with torch.no_grad():
+                fwd = m.score_net(x, t).numpy()
+        orig = torch.randn_like
+        torch.randn_like = _Replay(list(draws))
+        try:
+            with torch.no_grad():
+                b = m.sample({"perturbed": wav.clone(), "fake": fake.clone()}, N=3, corrector_steps=1, snr=0.5)
+        finally:
+            torch.randn_like = orig
+        out[sde_input] = b["enhanced" if sde_input == "noisy" else "fake_sde_enhanced"].numpy()
+    np.savez(os.path.join(OUT, "both.npz"), x=x.numpy(), t=t.numpy(), fwd=fwd, wav=wav.numpy(), fake=fake.numpy(),
+             out_sde_noisy=out["noisy"], out_sde_denoised=out["denoised"], N=3, corrector_steps=1, snr=0.5, noise_seed=4321, n_draws=7,
+             weights_seed=1234, weights_crc=crc)
+
+
 def gen_refine(model=None):
     """LSGAN refine stage: NCSNPP_Wrapper(n_fft=1022, hop=160, num_frames=480) = NCSNpp(discriminative=True)
     between STFT glue (GAN/generator/ncsnpp/model_wrapper.py:19-121, configs/model/LSGAN.yaml:46-53)."""
@@ -283,7 +316,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     small = {"fir": gen_fir, "resblocks": gen_resblocks, "attn": gen_attn, "samplers": gen_samplers, "samplers_em": gen_samplers_em,
-             "refine": gen_refine, "forward_small": gen_forward_small}
+             "refine": gen_refine, "forward_small": gen_forward_small, "both": gen_both}
     big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1,
            "sample_denoised": gen_sample_denoised}
     todo = [a.only] if a.only else list(small) + list(big)

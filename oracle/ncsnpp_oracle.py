@@ -134,8 +134,8 @@ def ncsnpp_forward(
         temb = None                                                           # ncsnpp.py:352, 364-370
         m = 1
     else:
-        # ncsnpp.py:333-347: channels = (x.re, x.im, y.re, y.im)
-        x4 = torch.cat([x[:, [0]].real, x[:, [0]].imag, x[:, [1]].real, x[:, [1]].imag], dim=1)
+        # ncsnpp.py:333-347: channels = (x.re, x.im, y.re, y.im) [+ (y2.re, y2.im): input_channels = 6, condition="both"]
+        x4 = torch.cat([p for k in range(x.shape[1]) for p in (x[:, [k]].real, x[:, [k]].imag)], dim=1)
         temb = time_embedding(t, sd)
         m = 3
     x4 = 2 * x4 - 1.0  # ncsnpp.py:372-374

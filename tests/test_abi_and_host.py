@@ -129,11 +129,13 @@ def test_score_model_state_dict_layout_and_no_cpu_fallback():
     with pytest.raises(_lib.UseHipError):
         z = torch.zeros(1, 1, 512, 64, dtype=torch.complex64)
         m(z, torch.ones(1), [z], z)
-    # the reference's constructor default condition="both" builds (6-channel parameter layout, checkpoints load) and refuses to run
+    # the reference's constructor default condition="both": 6-channel parameter layout, 3 complex inputs (CPU tensors refused)
     both = ScoreModel(backbone="ncsnpp", condition="both")
     assert both.state_dict()["score_net.output_layer.weight"].shape == (2, 6, 1, 1)
-    with pytest.raises(NotImplementedError):
-        both.score_net(torch.zeros(1, 3, 256, 64, dtype=torch.complex64))
+    with pytest.raises(ValueError):
+        both.score_net(torch.zeros(1, 2, 256, 64, dtype=torch.complex64), torch.ones(1))
+    with pytest.raises(_lib.UseHipError):
+        both.score_net(torch.zeros(1, 3, 256, 64, dtype=torch.complex64), torch.ones(1))
     with pytest.raises(ValueError):
         ScoreModel(backbone="no_such_backbone", condition="noisy")
 

@@ -670,3 +670,42 @@ def test_condition_denoised_matches_reference(golden_dir, sd_np, sde_input):
     assert _relmax(m._waveform(seam, 9600), out[key]) < 1e-4
     with pytest.raises(NotImplementedError):
         m.sample({"perturbed": batch["perturbed"]}, N=1)                    # condition="denoised" without batch["fake"]
+
+
+@pytest.mark.parametrize("sde_input", ["noisy", "denoised"])
+def test_condition_both_matches_reference(golden_dir, sde_input):
+    """ScoreModel(condition="both") -- the reference's constructor default (model_wrapper.py:26, 43-46): the 6-channel network sees
+    cat[x, Y, Y_denoised] (:287-288).  fp32 against outputs of the reference: one backbone forward (use_score2), ScoreModel.sample
+    through the fused loop (use_sample_cond2) for both choices of sde_input, the Python-driven seam path, and the 16-bit modes
+    within their drift bounds."""
+    from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel
+    g = dict(np.load(os.path.join(golden_dir, "both.npz")))
+    sd = tw.make_state_dict(int(g["weights_seed"]), **tw.LARGE_BOTH)
+    assert tw.weights_checksum(sd) == str(g["weights_crc"])
+
+    def model(prec):
+        m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition="both", n_fft=1022, hop_length=160, num_frames=512,
+                       window="hann", sde_input=sde_input, predictor="reverse_diffusion", corrector="langevin", precision=prec)
+        m.score_net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return m
+    m = model("fp32")
+    if sde_input == "noisy":
+        fwd = m.score_net(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda())
+        assert _relmax(fwd, g["fwd"]) < 5e-4
+    draws = torch.from_numpy(tnoise.sampler_noise(int(g["noise_seed"]), int(g["n_draws"]), (1, 1, 512, 64))).cuda()
+    batch = {"perturbed": torch.from_numpy(g["wav"]).cuda(), "fake": torch.from_numpy(g["fake"]).cuda()}
+    out = m.sample(dict(batch), N=int(g["N"]), corrector_steps=1, snr=0.5, noise=draws)
+    key = "enhanced" if sde_input == "noisy" else "fake_sde_enhanced"
+    assert _relmax(out[key], g["out_sde_" + sde_input]) < 2e-3
+    from universal_speech_enhancement_amd.sgmse import sampling
+    Y, Yd = m._spectrogram(batch["perturbed"]), m._spectrogram(batch["fake"])
+    sde = m.sde.copy(); sde.N = int(g["N"])
+    seam, _ = sampling.get_pc_sampler("reverse_diffusion", "langevin", sde=sde, y=Y if sde_input == "noisy" else Yd, eps=m.t_eps, snr=0.5,
+                                      corrector_steps=1, conditioning=[Y, Yd], noise=draws,
+                                      score_fn=lambda x, t, score_conditioning=None, sde_input=None: m(x, t, score_conditioning, sde_input))()
+    assert _relmax(m._waveform(seam, 9600), out[key]) < 1e-4
+    for prec, tol in (("bf16", 0.15), ("fp16", 0.03)):
+        o16 = model(prec).sample(dict(batch), N=int(g["N"]), corrector_steps=1, snr=0.5, noise=draws)
+        assert _relmax(o16[key], out[key]) < tol, prec
+    with pytest.raises(NotImplementedError):
+        m.sample({"perturbed": batch["perturbed"]}, N=1)                    # condition="both" without batch["fake"]

@@ -96,6 +96,19 @@ def test_forward_large_matches_reference(golden_dir, large_sd):
             assert err < 2e-5, (tag, err)
 
 
+def test_forward_six_channel_matches_reference(golden_dir):
+    """condition="both": NCSNppLarge(input_channels=6) on cat[x, Y, Y_denoised] (model_wrapper.py:43-46, ncsnpp.py:333-347)."""
+    g = _load(golden_dir, "both.npz")
+    sd_np = tw.make_state_dict(1234, **tw.LARGE_BOTH)
+    assert str(g["weights_crc"]) == tw.weights_checksum(sd_np)
+    assert sd_np["output_layer.weight"].shape == (2, 6, 1, 1) and sd_np["all_modules.3.weight"].shape == (128, 6, 3, 3)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    with torch.no_grad():
+        out = no.ncsnpp_forward(no.to_torch(sd_np), torch.from_numpy(g["x"]), torch.from_numpy(g["t"]))
+    err = np.abs(out.numpy() - g["fwd"]).max() / np.abs(g["fwd"]).max()
+    assert err < 2e-5, err
+
+
 @pytest.mark.slow
 def test_sample_e2e_matches_reference(golden_dir, large_sd):
     g = _load(golden_dir, "sample_e2e.npz")

@@ -60,6 +60,8 @@ SYMBOLS = {
     "use_workspace_bytes": (_i, [_vp, C.POINTER(C.c_size_t)]),
     "use_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "use_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "use_score2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "use_sample_cond2": (_i, [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp]),
     "use_set_sampler": (_i, [_vp, C.POINTER(UseSamplerConfig)]),
     "use_num_noise_draws": (_i, [_vp]),
     "use_get_timesteps": (_i, [_vp, C.POINTER(_f), _i]),

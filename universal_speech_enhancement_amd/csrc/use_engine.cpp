@@ -125,7 +125,8 @@ struct use_handle {
     size_t arena_alloc = 0, persist_alloc = 0;   // sizes of the two device allocations: kept at their high-water marks across re-plans
     float *x4 = nullptr, *silu_temb = nullptr, *tembias = nullptr, *t_dev = nullptr;
     float2 *Y = nullptr, *X = nullptr, *Xmean = nullptr, *score = nullptr, *xin = nullptr;
-    float2 *cond_buf = nullptr;
+    float2 *cond_buf = nullptr, *cond2_buf = nullptr;   // cond2: the second conditioning spectrogram of condition="both" (6 input channels)
+    int pcp = 4;                                 // input / pyramid channels as stored: the reference's 2, 4 or 6 zero-padded to 4 or 8
     float2 *Cond = nullptr;                      // score conditioning of the sampler: == Y unless use_sample_cond gave another
     float *lang_partial = nullptr, *lang_step = nullptr;
     unsigned long long* rng_state = nullptr;
@@ -210,8 +211,11 @@ static ResW make_res(use_handle* h, int idx, int in_ch, int out_ch, bool up, boo
 static int build_arch(use_handle* h) {
     const use_config& c = h->cfg;
     const int nf = c.nf, L = c.n_levels, nrb = c.num_res_blocks, dt = h->act_dtype;
-    // pc real input / pyramid channels in the reference tensors; stored zero-padded to 4 everywhere in the engine
+    // pc real input / pyramid channels in the reference tensors; stored zero-padded to pcp = 4 (8 for the 6 channels of
+    // condition="both", model_wrapper.py:43-46) everywhere in the engine
     const int pc = c.input_channels ? c.input_channels : 4;
+    const int pcp = pc > 4 ? 8 : 4;
+    h->pcp = pcp;
     add_expected(h, "output_layer.weight", {2, pc, 1, 1});
     add_expected(h, "output_layer.bias", {2});
     int m = 0;
@@ -220,7 +224,7 @@ static int build_arch(use_handle* h) {
         add_expected(h, "all_modules.1.weight", {4 * nf, 2 * nf}); add_expected(h, "all_modules.1.bias", {4 * nf}); m++;
         add_expected(h, "all_modules.2.weight", {4 * nf, 4 * nf}); add_expected(h, "all_modules.2.bias", {4 * nf}); m++;
     }
-    h->conv_in = make_conv(h, "all_modules." + std::to_string(m), 4, nf, 9, DT_F32, pc, 0); m++;   // fp32 input always
+    h->conv_in = make_conv(h, "all_modules." + std::to_string(m), pcp, nf, 9, DT_F32, pc, 0); m++;   // fp32 input always
     std::vector<int> hs_c{nf};
     int in_ch = nf;
     for (int lvl = 0; lvl < L; ++lvl) {
@@ -260,7 +264,7 @@ static int build_arch(use_handle* h) {
         }
         PyrW pw;
         pw.gn = make_gn(h, "all_modules." + std::to_string(m), in_ch); m++;
-        pw.conv = make_conv(h, "all_modules." + std::to_string(m), in_ch, 4, 9, dt, 0, pc); m++;
+        pw.conv = make_conv(h, "all_modules." + std::to_string(m), in_ch, pcp, 9, dt, 0, pc); m++;
         h->pyrs.push_back(pw);
         if (lvl != 0) h->res.push_back(make_res(h, m++, in_ch, in_ch, true, false));
     }
@@ -277,7 +281,7 @@ static int build_arch(use_handle* h) {
         if (w.has_wb) w.wb_off = take((size_t)w.ntaps * w.cout_pad * w.cin * dtype_size(w.w_dtype));
     };
     auto lay_gn = [&](GNW& g) { g.g_off = take((size_t)g.C * 4); g.b_off = take((size_t)g.C * 4); };
-    h->outw_off = take(8 * 4); h->outb_off = take(2 * 4);
+    h->outw_off = take((size_t)2 * pcp * 4); h->outb_off = take(2 * 4);
     h->gfp_off = take((size_t)nf * 4);
     h->l1w_off = take((size_t)4 * nf * 2 * nf * 4); h->l1b_off = take((size_t)4 * nf * 4);
     h->l2w_off = take((size_t)4 * nf * 4 * nf * 4); h->l2b_off = take((size_t)4 * nf * 4);
@@ -287,7 +291,7 @@ static int build_arch(use_handle* h) {
         lay_gn(r.gn0); lay_conv(r.c0); lay_gn(r.gn1); lay_conv(r.c1);
         if (r.has_c2) { lay_conv(r.c2); r.b12_off = take((size_t)r.out_ch * 4); }
     }
-    for (auto& cb : h->combines) { cb.w_off = take((size_t)cb.C * 4 * 4); cb.b_off = take((size_t)cb.C * 4); }
+    for (auto& cb : h->combines) { cb.w_off = take((size_t)cb.C * pcp * 4); cb.b_off = take((size_t)cb.C * 4); }
     lay_gn(h->attn.gn); lay_conv(h->attn.q); lay_conv(h->attn.k); lay_conv(h->attn.v); lay_conv(h->attn.o);
     for (auto& p : h->pyrs) { lay_gn(p.gn); lay_conv(p.conv); }
     h->blob_bytes = (off + 255) & ~(size_t)255;
@@ -344,11 +348,12 @@ static int pack_all(use_handle* h, char* blob) {
         const auto& v = h->host_w.at(name); memcpy(blob + off, v.data(), v.size() * 4);
     };
     const int pc = h->cfg.input_channels ? h->cfg.input_channels : 4;
-    auto cp_rows = [&](size_t off, const std::string& name, int rows) {     // [rows][pc] -> [rows][4], zero-padded
+    const int pcp = h->pcp;
+    auto cp_rows = [&](size_t off, const std::string& name, int rows) {     // [rows][pc] -> [rows][pcp], zero-padded
         const auto& v = h->host_w.at(name);
         float* d = (float*)(blob + off);
         for (int r = 0; r < rows; ++r)
-            for (int k = 0; k < 4; ++k) d[r * 4 + k] = k < pc ? v[(size_t)r * pc + k] : 0.f;
+            for (int k = 0; k < pcp; ++k) d[r * pcp + k] = k < pc ? v[(size_t)r * pc + k] : 0.f;
     };
     cp_rows(h->outw_off, "output_layer.weight", 2); cp(h->outb_off, "output_layer.bias");
     cp(h->gfp_off, "all_modules.0.W");
@@ -549,7 +554,8 @@ struct Fwd {
         st_arena->reset();
         if (!H->dry && st_arena->base) (void)hipMemsetAsync(st_arena->base, 0, st_arena->cap, s);   // all GroupNorm totals of this evaluation
         if (primary) { H->flops = 0.0; H->debug.clear(); H->debug_B = B; }
-        Act xin; xin.p = (void*)x4; xin.C = 4; xin.H = c.n_freq; xin.W = H->T; xin.dtype = DT_F32;
+        const int pcp = H->pcp;
+        Act xin; xin.p = (void*)x4; xin.C = pcp; xin.H = c.n_freq; xin.W = H->T; xin.dtype = DT_F32;
         std::vector<Act> hs;
         hs.push_back(conv(xin, nullptr, nullptr, 0, H->conv_in, nullptr, nullptr, 1.f, nullptr, nullptr, dt, true));
         if (primary) H->debug["h_in"] = hs.back();
@@ -559,10 +565,21 @@ struct Fwd {
             for (int k = 0; k < nrb; ++k) hs.push_back(resblock(hs.back(), nullptr, H->res[ri++]));
             if (lvl == std::min(g_stagger_level, L - 1) && ev_stagger && !H->dry) (void)hipEventRecord(ev_stagger, s);   // small maps follow
             if (lvl != L - 1) {
-                Act nip = new_act(4, ipyr.H / 2, ipyr.W / 2, DT_F32, false);          // pyramid_downsample
-                if (!H->dry) launch_fir_down2(ipyr.p, DT_F32, nullptr, 0, nullptr, nip.p, B, ipyr.H, ipyr.W, 4, s);
+                Act nip = new_act(pcp, ipyr.H / 2, ipyr.W / 2, DT_F32, false);        // pyramid_downsample
+                if (!H->dry) launch_fir_down2(ipyr.p, DT_F32, nullptr, 0, nullptr, nip.p, B, ipyr.H, ipyr.W, pcp, s);
                 ipyr = nip;
-                hs.push_back(resblock(hs.back(), nullptr, H->res[ri++], (const float*)ipyr.p, &H->combines[ci++]));
+                if (pcp == 4) {                                // Combine fused into the block's last convolution
+                    hs.push_back(resblock(hs.back(), nullptr, H->res[ri++], (const float*)ipyr.p, &H->combines[ci++]));
+                } else {                                       // 6-channel input: Combine as its own pass over the block's output
+                    Act o = resblock(hs.back(), nullptr, H->res[ri++]);
+                    const CombineW& cb = H->combines[ci++];
+                    if (!H->dry) {
+                        (void)hipMemsetAsync(o.stats, 0, (size_t)B * o.C * 2 * sizeof(long long), s);   // totals of the combined map
+                        launch_combine_add(o.p, o.dtype, (const float*)ipyr.p, W<float>(cb.w_off), W<float>(cb.b_off), o.stats, B,
+                                           (long)o.H * o.W, o.C, s);
+                    }
+                    hs.push_back(o);
+                }
             }
         }
         if (primary) H->debug["down_out"] = hs.back();
@@ -582,8 +599,8 @@ struct Fwd {
                 pyr = conv(hc, nullptr, &pw.gn, 1, pw.conv, nullptr, nullptr, 1.f, nullptr, nullptr, DT_F32, false);
                 have_pyr = true;
             } else {
-                Act up = new_act(4, pyr.H * 2, pyr.W * 2, DT_F32, false);               // pyramid_upsample
-                if (!H->dry) launch_fir_up2(pyr.p, DT_F32, nullptr, 0, nullptr, up.p, B, pyr.H, pyr.W, 4, s);
+                Act up = new_act(pcp, pyr.H * 2, pyr.W * 2, DT_F32, false);             // pyramid_upsample
+                if (!H->dry) launch_fir_up2(pyr.p, DT_F32, nullptr, 0, nullptr, up.p, B, pyr.H, pyr.W, pcp, s);
                 pyr = conv(hc, nullptr, &pw.gn, 1, pw.conv, nullptr, &up, 1.f, nullptr, nullptr, DT_F32, false);
             }
             if (lvl != 0) hc = resblock(hc, nullptr, H->res[ri++]);
@@ -606,16 +623,17 @@ static void run_temb(use_handle* h, const float* t, int n, float* silu_buf, floa
 
 // score = -net(cat[x, y], t): x, y device complex64
 static void run_score(use_handle* h, const float2* x, const float2* y, const float* tembias, int temb_bstride,
-                      const float* t, int t_stride, float2* out, hipStream_t s, float sign = -1.f) {
+                      const float* t, int t_stride, float2* out, hipStream_t s, float sign = -1.f, const float2* y2 = nullptr) {
     if (h->cfg.no_sigma_scale) t = nullptr;                   // score_out: no division by t
     const long n_per_b = (long)h->cfg.n_freq * h->T;
-    launch_pack_input(x, y, h->x4, (long)h->B * n_per_b, s);
+    const int pcp = h->pcp;
+    launch_pack_input(x, y, y2, h->x4, (long)h->B * n_per_b, s);
     const float* outw = (const float*)(h->blob + h->outw_off); const float* outb = (const float*)(h->blob + h->outb_off);
     if (h->nsub == 1) {
         Fwd f0{h, s, tembias, temb_bstride, t, t_stride};
         f0.B = h->B; f0.arena = &h->arena; f0.st_arena = &h->st_arena[0];
         Act pyr = f0.run(h->x4);
-        launch_score_out((const float*)pyr.p, t, t_stride, outw, outb, out, h->B, n_per_b, sign, s);
+        launch_score_out((const float*)pyr.p, pcp, t, t_stride, outw, outb, out, h->B, n_per_b, sign, s);
         return;
     }
     // Sub-batches on separate streams.  The items are independent inside the network (GroupNorm is per item), so this is
@@ -635,8 +653,8 @@ static void run_score(use_handle* h, const float2* x, const float2* y, const flo
               t ? t + (size_t)b0 * t_stride : nullptr, t_stride};
         f.B = h->sub_B[i]; f.arena = i ? &h->sub_arena[i] : &h->arena; f.st_arena = &h->st_arena[i]; f.primary = i == 0;
         if (overlap && i + 1 < h->nsub) f.ev_stagger = h->ev_stagger[i];
-        Act pyr = f.run(h->x4 + (size_t)b0 * n_per_b * 4);
-        launch_score_out((const float*)pyr.p, t ? t + (size_t)b0 * t_stride : nullptr, t_stride, outw, outb,
+        Act pyr = f.run(h->x4 + (size_t)b0 * n_per_b * pcp);
+        launch_score_out((const float*)pyr.p, pcp, t ? t + (size_t)b0 * t_stride : nullptr, t_stride, outw, outb,
                          out + (size_t)b0 * n_per_b, h->sub_B[i], n_per_b, sign, si);
         if (overlap && i) (void)hipEventRecord(h->ev_join[i], si);
         b0 += h->sub_B[i];
@@ -696,7 +714,7 @@ static void run_sampler(use_handle* h, const float2* noise, hipStream_t s, int i
         const float t = h->timesteps[i];
         const float* temb = h->temb_table + (size_t)i * h->dense_rows;
         for (int k = 0; k < ncorr; ++k) {
-            run_score(h, h->X, h->Cond, temb, 0, h->ts_dev + i, 0, h->score, s);
+            run_score(h, h->X, h->Cond, temb, 0, h->ts_dev + i, 0, h->score, s, -1.f, h->pcp == 8 ? h->cond2_buf : nullptr);
             RngRef rr{h->rng_state, d};
             if (sc.corrector == USE_CORR_LANGEVIN) {
                 launch_langevin_norms(h->score, nz(d), rr, h->lang_partial, h->B, n_per_b, h->lang_blocks, s);
@@ -711,7 +729,7 @@ static void run_sampler(use_handle* h, const float2* noise, hipStream_t s, int i
         if (sc.predictor == USE_PRED_NONE) {
             if (i == sc.N - 1) (void)hipMemcpyAsync(h->Xmean, h->X, (size_t)n * 8, hipMemcpyDeviceToDevice, s);
         } else {
-            run_score(h, h->X, h->Cond, temb, 0, h->ts_dev + i, 0, h->score, s);
+            run_score(h, h->X, h->Cond, temb, 0, h->ts_dev + i, 0, h->score, s, -1.f, h->pcp == 8 ? h->cond2_buf : nullptr);
             float cd, cs, cn; predictor_coeffs(h->cfg, sc.predictor, t, sc.N, cd, cs, cn);
             launch_predictor(h->X, h->Y, h->score, nz(d), RngRef{h->rng_state, d}, cd, cs, cn, h->X,
                              i == sc.N - 1 ? h->Xmean : nullptr, n, s);
@@ -774,8 +792,8 @@ int use_create(const use_config* cfg, int device, use_handle** out) {
     if (cfg->n_freq % (1 << (cfg->n_levels - 1)) != 0)
         return fail(USE_E_INVALID, "n_freq=%d is not divisible by 2^(levels-1)", cfg->n_freq);
     if (cfg->precision != USE_PREC_FP32 && cfg->precision != USE_PREC_BF16 && cfg->precision != USE_PREC_FP16) return fail(USE_E_INVALID, "bad precision");
-    if (cfg->input_channels != 0 && cfg->input_channels != 2 && cfg->input_channels != 4)
-        return fail(USE_E_INVALID, "input_channels must be 4 (x and y) or 2 (y alone), got %d", cfg->input_channels);
+    if (cfg->input_channels != 0 && cfg->input_channels != 2 && cfg->input_channels != 4 && cfg->input_channels != 6)
+        return fail(USE_E_INVALID, "input_channels must be 4 (x and y), 6 (x, y and a second conditioning) or 2 (y alone), got %d", cfg->input_channels);
     use_handle* h = new use_handle();
     h->cfg = *cfg; h->device = device;
     h->act_dtype = cfg->precision == USE_PREC_BF16 ? DT_BF16 : cfg->precision == USE_PREC_FP16 ? DT_F16 : DT_F32;
@@ -1001,7 +1019,7 @@ int use_plan(use_handle* h, int B, int Tpad) {
     h->lang_blocks = (int)std::min<size_t>(256, ((size_t)h->cfg.n_freq * Tpad + 255) / 256);
     size_t off = 0;
     auto take = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; size_t o = off; off += bytes; return o; };
-    const size_t o_x4 = take(n * 16), o_Y = take(n * 8), o_X = take(n * 8), o_Xm = take(n * 8), o_sc = take(n * 8),
+    const size_t o_x4 = take(n * 4 * h->pcp), o_c2 = take(h->pcp == 8 ? n * 8 : 0), o_Y = take(n * 8), o_X = take(n * 8), o_Xm = take(n * 8), o_sc = take(n * 8),
                  o_xin = take(n * 8), o_cond = take(n * 8), o_st = take((size_t)B * 4 * h->cfg.nf * 4), o_tb = take((size_t)B * h->dense_rows * 4),
                  o_t = take((size_t)B * 4), o_lp = take((size_t)B * h->lang_blocks * 2 * 4), o_ls = take(256), o_rng = take(256);
     h->persist_bytes = off;
@@ -1013,6 +1031,7 @@ int use_plan(use_handle* h, int B, int Tpad) {
     h->x4 = (float*)(h->persist + o_x4); h->Y = (float2*)(h->persist + o_Y); h->X = (float2*)(h->persist + o_X);
     h->Xmean = (float2*)(h->persist + o_Xm); h->score = (float2*)(h->persist + o_sc); h->xin = (float2*)(h->persist + o_xin);
     h->cond_buf = (float2*)(h->persist + o_cond); h->Cond = h->Y;
+    h->cond2_buf = h->pcp == 8 ? (float2*)(h->persist + o_c2) : nullptr;
     h->silu_temb = (float*)(h->persist + o_st); h->tembias = (float*)(h->persist + o_tb); h->t_dev = (float*)(h->persist + o_t);
     h->lang_partial = (float*)(h->persist + o_lp); h->lang_step = (float*)(h->persist + o_ls);
     h->rng_state = (unsigned long long*)(h->persist + o_rng);
@@ -1036,18 +1055,25 @@ static int check_ready(use_handle* h) {
 }
 
 // one network evaluation; sign -1: the score (use_score), +1: the raw backbone output (use_forward)
-static int eval_net(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream, float sign) {
+static int eval_net(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream, float sign,
+                    const void* y2 = nullptr) {
     int rc = check_ready(h); if (rc) return rc;
     const use_config& c = h->cfg;
     const bool two_ch = c.input_channels == 2;
     if (!x || !out) return fail(USE_E_INVALID, "null tensor");
+    if ((c.input_channels == 6) != (y2 != nullptr))
+        return fail(USE_E_INVALID, c.input_channels == 6 ? "a 6-channel network takes two conditioning tensors (use_score2)" : "this network takes one conditioning tensor");
     if (two_ch ? y != nullptr : y == nullptr) return fail(USE_E_INVALID, two_ch ? "a 2-channel network takes x alone (y must be null)" : "null tensor");
     if (!t && (!c.unconditional || !c.no_sigma_scale)) return fail(USE_E_INVALID, "this network needs the time t");
     hipStream_t s = (hipStream_t)stream;
     if (!c.unconditional) run_temb(h, t, h->B, h->silu_temb, h->tembias, s);
-    run_score(h, (const float2*)x, (const float2*)y, c.unconditional ? nullptr : h->tembias, h->dense_rows, t, 1, (float2*)out, s, sign);
+    run_score(h, (const float2*)x, (const float2*)y, c.unconditional ? nullptr : h->tembias, h->dense_rows, t, 1, (float2*)out, s, sign,
+              (const float2*)y2);
     HIPCHK(hipGetLastError());
     return USE_OK;
+}
+int use_score2(use_handle* h, const void* x, const void* y, const void* y2, const float* t, void* out, use_stream_t stream) {
+    return eval_net(h, x, y, t, out, stream, -1.f, y2);
 }
 int use_score(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream) {
     return eval_net(h, x, y, t, out, stream, -1.f);
@@ -1138,12 +1164,21 @@ int use_sample(use_handle* h, const void* y, const void* noise, uint64_t seed, v
 }
 
 int use_sample_cond(use_handle* h, const void* y, const void* cond, const void* noise, uint64_t seed, void* out, use_stream_t stream) {
+    return use_sample_cond2(h, y, cond, nullptr, noise, seed, out, stream);
+}
+
+int use_sample_cond2(use_handle* h, const void* y, const void* cond, const void* cond2, const void* noise, uint64_t seed, void* out,
+                     use_stream_t stream) {
     int rc = check_ready(h); if (rc) return rc;
     if (!h->sampler_set) return fail(USE_E_STATE, "use_set_sampler has not been called");
     if (!y || !out) return fail(USE_E_INVALID, "null tensor");
+    if ((h->cfg.input_channels == 6) != (cond2 != nullptr))
+        return fail(USE_E_INVALID, h->cfg.input_channels == 6 ? "a 6-channel network samples with two conditioning tensors (use_sample_cond2)"
+                                                              : "this network takes one conditioning tensor");
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)h->B * h->cfg.n_freq * h->T;
     HIPCHK(hipMemcpyAsync(h->Y, y, n * 8, hipMemcpyDeviceToDevice, s));
+    if (cond2) HIPCHK(hipMemcpyAsync(h->cond2_buf, cond2, n * 8, hipMemcpyDeviceToDevice, s));
     {   // the conditioning spectrogram the network sees beside x: the SDE's y itself, or a separate one (condition="denoised")
         float2* want = cond ? h->cond_buf : h->Y;
         if (want != h->Cond) { HIPCHK(hipStreamSynchronize(s)); drop_graphs(h); h->Cond = want; }    // captured graphs hold the pointer

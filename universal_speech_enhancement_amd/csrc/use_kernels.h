@@ -109,8 +109,13 @@ void launch_stft_fwd(const float* wav, const float* win, const float2* tw, float
 void launch_istft_back(const float2* X, const float* win, const float2* tw, float* wav, int B, int L, int N, int hop, int Tpad,
                        float factor, float expo, hipStream_t s);
 
-// x4[b,f,t,:] = 2*(x.re, x.im, y.re, y.im) - 1   (fp32), x/y complex64 [B,F,T]
-void launch_pack_input(const float2* x, const float2* y, float* x4, long npix, hipStream_t s);
+// x4[b,f,t,:] = 2*(x.re, x.im, y.re, y.im) - 1   (fp32), x/y complex64 [B,F,T]; y2 != null: 8 channels per pixel,
+// 2*(x, y, y2) - 1 and two zero channels (the 6-channel input of condition="both")
+void launch_pack_input(const float2* x, const float2* y, const float2* y2, float* x4, long npix, hipStream_t s);
+// Combine 'sum' of an 8-channel (6 + 2 padding) input pyramid as its own pass (reference layerspp.py:50-55): in place
+// h[b,p,:] += b8 + W8 . pyr[b,p,:], and the GroupNorm totals of the stored values into stats (zeroed by the caller)
+void launch_combine_add(void* h, int dtype, const float* pyr, const float* w8, const float* b8, long long* stats, int B, long pix_per_b,
+                        int C, hipStream_t s);
 
 // Time embedding: t[B] -> silu(Linear2(silu(Linear1(fourier(log t)))))  [B][4nf]
 void launch_temb_mlp(const float* t, int t_stride, const float* gfp_w, const float* w1, const float* b1,
@@ -128,8 +133,8 @@ void launch_softmax_rows(void* x, int dtype, long rows, int cols, hipStream_t s)
 void launch_transpose_nc(const void* in, void* out, int dtype, int B, int N, int C, hipStream_t s);   // [B][N][C] -> [B][C][N]
 
 // net = conv1x1_{4->2}(pyr / t[b]) (t == null: no division); out = sign * net  (complex64 out; sign -1: the score)
-void launch_score_out(const float* pyr, const float* t, int t_stride, const float* w, const float* bias,
-                      float2* score, int B, long pix_per_b, float sign, hipStream_t s);
+void launch_score_out(const float* pyr, int pc, const float* t, int t_stride, const float* w, const float* bias,
+                      float2* score, int B, long pix_per_b, float sign, hipStream_t s);     // pc = 4 or 8 pyramid channels
 
 // ---- SDE updates (complex64 as float2, fp32 arithmetic) ----
 struct RngRef { const unsigned long long* state; unsigned draw; };  // state[0]=seed, state[1]=draw base

@@ -1080,16 +1080,78 @@ void launch_istft_back(const float2* X, const float* win, const float2* tw, floa
 // Input packing
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_input_kernel(const float2* __restrict__ x, const float2* __restrict__ y,
-                                                         float4* __restrict__ x4, long npix) {
+                                                         const float2* __restrict__ y2, float4* __restrict__ x4, long npix) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
         const float2 a = x[i];
         // y == null: a 2-channel network (NCSNpp(discriminative=True)); the two padding channels meet zero weights
         const float2 c = y ? y[i] : make_float2(0.5f, 0.5f);
-        x4[i] = make_float4(2.f * a.x - 1.f, 2.f * a.y - 1.f, 2.f * c.x - 1.f, 2.f * c.y - 1.f);
+        const float4 v = make_float4(2.f * a.x - 1.f, 2.f * a.y - 1.f, 2.f * c.x - 1.f, 2.f * c.y - 1.f);
+        if (y2) {                                            // 6 channels (+ 2 of padding that meet zero weights)
+            const float2 d = y2[i];
+            x4[2 * i] = v;
+            x4[2 * i + 1] = make_float4(2.f * d.x - 1.f, 2.f * d.y - 1.f, 0.f, 0.f);
+        } else {
+            x4[i] = v;
+        }
     }
 }
-void launch_pack_input(const float2* x, const float2* y, float* x4, long npix, hipStream_t s) {
-    hipLaunchKernelGGL(pack_input_kernel, dim3(ew_blocks(npix)), dim3(256), 0, s, x, y, (float4*)x4, npix);
+void launch_pack_input(const float2* x, const float2* y, const float2* y2, float* x4, long npix, hipStream_t s) {
+    hipLaunchKernelGGL(pack_input_kernel, dim3(ew_blocks(npix)), dim3(256), 0, s, x, y, y2, (float4*)x4, npix);
+}
+
+// Combine 'sum' with an 8-channel pyramid as its own pass (6-channel network input only; the 4-channel case is fused into the
+// producing convolution's epilogue).  One block = 64 consecutive pixels of one item x all C channels, a thread owns one
+// 16-byte channel chunk and walks the pixels; per-channel totals of the stored values through LDS in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void combine_add_kernel(T* __restrict__ h, const float* __restrict__ pyr, const float* __restrict__ w8,
+                                                          const float* __restrict__ b8, long long* __restrict__ stats, long pix_per_b, int C) {
+    constexpr int CH = Vec16<T>::N;
+    __shared__ float s_w[512 * 8];
+    __shared__ float s_red[256 * CH * 2];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cpr = C / CH;                                  // chunks per pixel (C <= 512, C % CH == 0; cpr <= 256)
+    for (int i = tid; i < C * 8; i += 256) s_w[i] = w8[i];
+    __syncthreads();
+    const int ch = tid % cpr, prow = tid / cpr, pstep = 256 / cpr;
+    const bool active = prow < pstep;                        // 256 % cpr != 0: the last partial row of threads idles
+    float st_s[CH], st_q[CH], bias[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { st_s[c] = 0.f; st_q[c] = 0.f; bias[c] = b8[ch * CH + c]; }
+    const long p0 = (long)blockIdx.x * 64;
+    if (active)
+        for (long pi = p0 + prow; pi < p0 + 64 && pi < pix_per_b; pi += pstep) {
+            const size_t pix = (size_t)b * pix_per_b + pi;
+            const float4 q0 = *reinterpret_cast<const float4*>(pyr + pix * 8), q1 = *reinterpret_cast<const float4*>(pyr + pix * 8 + 4);
+            float v[CH];
+            Vec16<T>::load(h + pix * C + ch * CH, v);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const float* wr = s_w + (ch * CH + c) * 8;
+                v[c] += bias[c] + wr[0] * q0.x + wr[1] * q0.y + wr[2] * q0.z + wr[3] * q0.w + wr[4] * q1.x + wr[5] * q1.y + wr[6] * q1.z + wr[7] * q1.w;
+            }
+            const uint4 packed = Vec16<T>::pack(v);
+            *reinterpret_cast<uint4*>(h + pix * C + ch * CH) = packed;
+            float vr[CH];
+            Vec16<T>::load(reinterpret_cast<const T*>(&packed), vr);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { st_s[c] += vr[c]; st_q[c] += vr[c] * vr[c]; }
+        }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { s_red[(tid * CH + c) * 2] = st_s[c]; s_red[(tid * CH + c) * 2 + 1] = st_q[c]; }
+    __syncthreads();
+    for (int co = tid; co < C; co += 256) {
+        const int cc = co / CH, c = co % CH;
+        float sm = 0.f, q = 0.f;
+        for (int r = 0; r < pstep; ++r) { sm += s_red[((r * cpr + cc) * CH + c) * 2]; q += s_red[((r * cpr + cc) * CH + c) * 2 + 1]; }
+        gn_accumulate(stats + ((size_t)b * C + co) * 2, sm, q);
+    }
+}
+void launch_combine_add(void* h, int dtype, const float* pyr, const float* w8, const float* b8, long long* stats, int B, long pix_per_b,
+                        int C, hipStream_t s) {
+    const dim3 grid((unsigned)((pix_per_b + 63) / 64), B);
+    if (dtype == DT_F32)       hipLaunchKernelGGL(combine_add_kernel<float>, grid, dim3(256), 0, s, (float*)h, pyr, w8, b8, stats, pix_per_b, C);
+    else if (dtype == DT_F16)  hipLaunchKernelGGL(combine_add_kernel<_Float16>, grid, dim3(256), 0, s, (_Float16*)h, pyr, w8, b8, stats, pix_per_b, C);
+    else                       hipLaunchKernelGGL(combine_add_kernel<__bf16>, grid, dim3(256), 0, s, (__bf16*)h, pyr, w8, b8, stats, pix_per_b, C);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1247,27 +1309,38 @@ void launch_transpose_nc(const void* in, void* out, int dtype, int B, int N, int
 // ---------------------------------------------------------------------------------------------------------
 // Output layer + SDE updates
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void score_out_kernel(const float4* __restrict__ pyr, const float* __restrict__ t,
+template <int PC>
+__global__ __launch_bounds__(256) void score_out_kernel(const float* __restrict__ pyr, const float* __restrict__ t,
                                                         int t_stride, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float2* __restrict__ score,
                                                         long pix_per_b, float sign) {
     const int b = blockIdx.y;
     const float tv = t ? t[(size_t)b * t_stride] : 1.0f;      // t == null: scale_by_sigma=False
-    const float w00 = w[0], w01 = w[1], w02 = w[2], w03 = w[3], w10 = w[4], w11 = w[5], w12 = w[6], w13 = w[7];
+    float wr[PC], wi[PC];
+#pragma unroll
+    for (int k = 0; k < PC; ++k) { wr[k] = w[k]; wi[k] = w[PC + k]; }
     const float b0 = bias[0], b1 = bias[1];
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pix_per_b; i += (long)gridDim.x * 256) {
-        float4 h = pyr[(size_t)b * pix_per_b + i];
-        if (t) { h.x /= tv; h.y /= tv; h.z /= tv; h.w /= tv; }   // h / used_sigmas (ncsnpp.py:492-494)
-        const float re = b0 + w00 * h.x + w01 * h.y + w02 * h.z + w03 * h.w;
-        const float im = b1 + w10 * h.x + w11 * h.y + w12 * h.z + w13 * h.w;
+        float hv[PC];
+#pragma unroll
+        for (int k4 = 0; k4 < PC / 4; ++k4) {
+            const float4 q = *reinterpret_cast<const float4*>(pyr + ((size_t)b * pix_per_b + i) * PC + k4 * 4);
+            hv[k4 * 4] = q.x; hv[k4 * 4 + 1] = q.y; hv[k4 * 4 + 2] = q.z; hv[k4 * 4 + 3] = q.w;
+        }
+        float re = b0, im = b1;
+#pragma unroll
+        for (int k = 0; k < PC; ++k) {
+            const float hk = t ? hv[k] / tv : hv[k];           // h / used_sigmas (ncsnpp.py:492-494)
+            re += wr[k] * hk; im += wi[k] * hk;
+        }
         score[(size_t)b * pix_per_b + i] = make_float2(sign * re, sign * im);  // sign -1: score = -score_net(...) (model_wrapper.py:137)
     }
 }
-void launch_score_out(const float* pyr, const float* t, int t_stride, const float* w, const float* bias,
+void launch_score_out(const float* pyr, int pc, const float* t, int t_stride, const float* w, const float* bias,
                       float2* score, int B, long pix_per_b, float sign, hipStream_t s) {
     int bx = (int)((pix_per_b + 255) / 256); if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(score_out_kernel, dim3(bx, B), dim3(256), 0, s, (const float4*)pyr, t, t_stride, w, bias, score,
-                       pix_per_b, sign);
+    if (pc == 8) hipLaunchKernelGGL(score_out_kernel<8>, dim3(bx, B), dim3(256), 0, s, pyr, t, t_stride, w, bias, score, pix_per_b, sign);
+    else         hipLaunchKernelGGL(score_out_kernel<4>, dim3(bx, B), dim3(256), 0, s, pyr, t, t_stride, w, bias, score, pix_per_b, sign);
 }
 
 // Philox4x32-10 counter RNG -> complex normal with E|z|^2 = 1 (torch.randn_like(complex) law).

@@ -198,10 +198,13 @@ class HipScoreEngine:
         return float(self.L.use_flops_per_score(self.h))
 
     # ---- execution ----------------------------------------------------------------------------------
-    def score(self, x: torch.Tensor, y: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
-        """-score_net(cat[x, y], t): x, y complex64 [B,1,F,T'] on this device, t float32 [B]."""
+    def score(self, x: torch.Tensor, y: torch.Tensor, t: torch.Tensor, y2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """-score_net(cat[x, y], t): x, y complex64 [B,1,F,T'] on this device, t float32 [B].  ``y2``: the second conditioning
+        spectrogram of a 6-channel network (condition="both"; ``use_score2``)."""
         x = _require_cuda_c64("x", x)
         y = _require_cuda_c64("y", y, x.shape)
+        if y2 is not None:
+            y2 = _require_cuda_c64("y2", y2, x.shape)
         B, _, Fq, T = x.shape
         if Fq != self.n_freq:
             raise ValueError(f"expected {self.n_freq} frequency bins, got {Fq}")
@@ -210,7 +213,11 @@ class HipScoreEngine:
         if t.numel() != B:
             raise ValueError(f"t must have {B} elements")
         out = torch.empty_like(x)
-        check(self.L.use_score(self.h, x.data_ptr(), y.data_ptr(), t.data_ptr(), out.data_ptr(), _stream_ptr(x.device)), "use_score")
+        if y2 is not None:
+            check(self.L.use_score2(self.h, x.data_ptr(), y.data_ptr(), y2.data_ptr(), t.data_ptr(), out.data_ptr(), _stream_ptr(x.device)),
+                  "use_score2")
+        else:
+            check(self.L.use_score(self.h, x.data_ptr(), y.data_ptr(), t.data_ptr(), out.data_ptr(), _stream_ptr(x.device)), "use_score")
         return out
 
     def forward(self, x: torch.Tensor, y: Optional[torch.Tensor] = None, t: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -261,11 +268,13 @@ class HipScoreEngine:
         return np.array(buf[:], dtype=np.float32)
 
     def sample(self, y: torch.Tensor, noise: Optional[torch.Tensor] = None, seed: int = 0,
-               cond: Optional[torch.Tensor] = None) -> torch.Tensor:
+               cond: Optional[torch.Tensor] = None, cond2: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Run the configured PC sampler on y (complex64 [B,1,F,T']); returns x_mean of the last step.  ``cond``: score
-        conditioning when it is not y itself (``use_sample_cond``)."""
+        conditioning when it is not y itself (``use_sample_cond``); ``cond2``: the second conditioning spectrogram of a
+        6-channel network (``use_sample_cond2``)."""
         y = _require_cuda_c64("y", y)
         cptr = None if cond is None or cond is y else _require_cuda_c64("cond", cond, y.shape).data_ptr()
+        c2ptr = None if cond2 is None else _require_cuda_c64("cond2", cond2, y.shape).data_ptr()
         if (y.shape[0], y.shape[3]) != self.plan_shape:
             raise UseHipError(f"sampler planned for {self.plan_shape}, got B={y.shape[0]} T'={y.shape[3]}")
         nptr = None
@@ -273,8 +282,8 @@ class HipScoreEngine:
             noise = _require_cuda_c64("noise", noise, (self.num_noise_draws(),) + tuple(y.shape))
             nptr = noise.data_ptr()
         out = torch.empty_like(y)
-        check(self.L.use_sample_cond(self.h, y.data_ptr(), cptr, nptr, int(seed) & (2**64 - 1), out.data_ptr(), _stream_ptr(y.device)),
-              "use_sample_cond")
+        check(self.L.use_sample_cond2(self.h, y.data_ptr(), cptr, c2ptr, nptr, int(seed) & (2**64 - 1), out.data_ptr(),
+                                      _stream_ptr(y.device)), "use_sample_cond2")
         return out
 
     def debug_tensor(self, name: str) -> torch.Tensor:

@@ -54,9 +54,8 @@ class NCSNpp(nn.Module):
         if self.discriminative:      # reference ncsnpp.py:86-92: options that make no sense for a discriminative model
             conditional, scale_by_sigma, input_channels = False, False, 2
         if input_channels not in (2, 4, 6):
-            raise NotImplementedError("NCSNpp(HIP): input_channels must be 4 (condition='noisy' / 'denoised'), 2 (discriminative) or 6")
-        # input_channels = 6 (condition='both', the reference's constructor default): the module holds the parameters under the
-        # reference's keys and shapes (checkpoints load), but libuse_hip.so has no 6-channel input path -- forward() raises
+            raise NotImplementedError("NCSNpp(HIP): input_channels must be 4 (condition='noisy' / 'denoised'), 2 (discriminative) or "
+                                      "6 (condition='both')")
         self.conditional, self.scale_by_sigma = bool(conditional), bool(scale_by_sigma)
         self.nf, self.ch_mult, self.num_res_blocks = nf, tuple(ch_mult), num_res_blocks
         self.input_channels, self.precision, self.n_freq = input_channels, precision, n_freq
@@ -111,16 +110,10 @@ class NCSNpp(nn.Module):
                               theta=th, sigma_min=smin, sigma_max=smax, input_channels=self.input_channels,
                               conditional=self.conditional, scale_by_sigma=self.scale_by_sigma)
 
-    def _check_runnable(self):
-        if self.input_channels == 6:
-            raise NotImplementedError("NCSNpp(HIP): the 6-channel network (condition='both') is not implemented in libuse_hip.so; "
-                                      "use condition='noisy' or 'denoised'")
-
     def engine(self, n_freq: int, device=None, sde_constants=None):
         """The ``use_handle`` for ``n_freq`` bins (and the OUVE constants of the fused sampler); rebuilt when either
         changes.  Weights come from the packed file when ``load_weight_file`` was used, else from the module's
         parameters."""
-        self._check_runnable()
         want = tuple(float(v) for v in (sde_constants or self._engine_sde))
         if self._engine is None or self._engine.n_freq != n_freq or self._engine_sde != want:
             self._engine = self._new_engine(n_freq, device, want)
@@ -148,10 +141,10 @@ class NCSNpp(nn.Module):
         self._engine_dirty, self._weight_file = True, None
 
     def forward(self, x: torch.Tensor, time_cond: torch.Tensor = None) -> torch.Tensor:
-        self._check_runnable()
         nin = self.input_channels // 2
         if x.dim() != 4 or x.shape[1] != nin:
             raise ValueError("expected complex input [B, 2, F, T'] = cat([x_t, Y], dim=1)" if nin == 2 else
+                             "expected complex input [B, 3, F, T'] = cat([x_t, Y, Y_denoised], dim=1)" if nin == 3 else
                              "expected complex input [B, 1, F, T'] (discriminative network)")
         if not x.is_cuda:
             from ...hip_engine import UseHipError
@@ -161,6 +154,8 @@ class NCSNpp(nn.Module):
         eng = self.engine(x.shape[2], x.device)
         if nin == 1:
             return eng.forward(x, None, time_cond if (self.conditional or self.scale_by_sigma) else None)
+        if nin == 3:                                         # condition="both": forward = -score (use_score2)
+            return -eng.score(x[:, 0:1], x[:, 1:2], time_cond, y2=x[:, 2:3])
         return eng.forward(x[:, 0:1], x[:, 1:2], time_cond)
 
 

@@ -51,14 +51,14 @@ class ScoreModel(SpectralGlue, nn.Module):
 
     # ---- samplers (reference :210-260) -------------------------------------------------------------------
     def fused_sample(self, y, N, predictor, corrector, corrector_steps, snr, t_eps, noise=None, seed=0, use_graph=True,
-                     sde=None, cond=None):
-        """Whole PC loop inside libuse_hip.so (``use_sample_cond``), with the OUVE constants of ``sde`` (default: ``self.sde``);
-        ``cond``: the score conditioning when it is not ``y`` itself."""
+                     sde=None, cond=None, cond2=None):
+        """Whole PC loop inside libuse_hip.so (``use_sample_cond2``), with the OUVE constants of ``sde`` (default: ``self.sde``);
+        ``cond``: the score conditioning when it is not ``y`` itself; ``cond2``: the second one of condition="both"."""
         sde = self.sde if sde is None else sde
         eng = self.score_net.engine(y.shape[2], y.device, sde_constants=(sde.theta, sde.sigma_min, sde.sigma_max))
         eng.plan(y.shape[0], y.shape[3])
         eng.set_sampler(N, predictor, corrector, corrector_steps, snr, t_eps, use_graph=use_graph)
-        return eng.sample(y, noise=noise, seed=seed, cond=cond)
+        return eng.sample(y, noise=noise, seed=seed, cond=cond, cond2=cond2)
 
     def get_pc_sampler(self, predictor_name, corrector_name, y, N=None, minibatch=None, **kwargs):
         N = self.sde.N if N is None else N
@@ -96,8 +96,7 @@ class ScoreModel(SpectralGlue, nn.Module):
         elif self.condition == "denoised" and Y_denoised is not None:
             score_conditioning = [Y_denoised]
         elif self.condition == "both" and Y_denoised is not None:
-            raise NotImplementedError("condition='both' needs the 6-channel network input, which libuse_hip.so does not implement "
-                                      "(no shipped config selects it; 'noisy' and 'denoised' are served)")
+            score_conditioning = [Y, Y_denoised]
         else:
             raise NotImplementedError(f"Don't know the conditioning you have wished for: {self.condition}")
         # the SDE's y (reference :293-300)

@@ -55,14 +55,15 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=Tru
     # its constants travel with the call so that the engine is rebuilt when they differ from the defaults
     fused = (builtin and type(sde) is OUVESDE and not probability_flow and denoise
              and getattr(score_fn, "supports_fused_sampler", False)
-             and conditioning is not None and len(conditioning) == 1 and conditioning[0].shape == y.shape)
+             and conditioning is not None and len(conditioning) in (1, 2) and all(c.shape == y.shape for c in conditioning))
 
     if fused:
         def pc_sampler():
             with torch.no_grad():
                 x = score_fn.fused_sample(y, N=sde.N, predictor=predictor_name, corrector=corrector_name,
                                           corrector_steps=corrector_steps, snr=snr, t_eps=eps, noise=noise, seed=seed,
-                                          use_graph=use_graph, sde=sde, cond=conditioning[0])
+                                          use_graph=use_graph, sde=sde, cond=conditioning[0],
+                                          cond2=conditioning[1] if len(conditioning) == 2 else None)
             return x, sde.N * (corrector.n_steps + 1)
         return pc_sampler
 

@@ -103,6 +103,7 @@ def weights_checksum(sd: Dict[str, np.ndarray]) -> str:
 
 
 LARGE = dict(nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, input_channels=4)
+LARGE_BOTH = dict(nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, input_channels=6)    # ScoreModel(condition="both")
 SMALL12M = dict(nf=96, ch_mult=(1, 2, 2, 1), num_res_blocks=1, input_channels=4)      # NCSNpp12M (reference ncsnpp.py:527-541)
 SMALL6M = dict(nf=96, ch_mult=(1, 1, 1, 1), num_res_blocks=1, input_channels=4)       # NCSNpp6M (reference ncsnpp.py:545-559)
 # NCSNpp(discriminative=True): the generator of the LSGAN refine stage (reference ncsnpp.py:42-69 defaults + 86-92)
