@@ -293,6 +293,41 @@ def gen_both(model=None):
              weights_seed=1234, weights_crc=crc)
 
 
+def gen_train_loss(model=None):
+    """ScoreModel.train_step (model_wrapper.py:147-208) = the value validation_step / test_step log (SGMSE_module.py:56-63), with
+    the three random draws pinned (np.random.uniform -> start, torch.rand -> t, torch.randn_like -> z).  num_frames=64 keeps the
+    fixture small (target_len 10080 samples, T = 64 frames).  Case a: condition noisy, 12000-sample clips (random excerpt), mse;
+    case b: condition both / sde_input denoised, 8000-sample clips (zero padding), mse and mae."""
+    import src.models.components.sgmse.model_wrapper as MW
+    out = {}
+    for tag, cond, sde_in, L, arch in (("a", "noisy", "noisy", 12000, tw.LARGE), ("b", "both", "denoised", 8000, tw.LARGE_BOTH)):
+        clean = torch.from_numpy(tnoise.synth_noisy_speech(2, L, seed=91))
+        noisy = 0.8 * clean + 0.2 * torch.from_numpy(tnoise.synth_noisy_speech(2, L, seed=92))
+        fake = 0.9 * clean + 0.1 * torch.from_numpy(tnoise.synth_noisy_speech(2, L, seed=93))
+        t = torch.tensor([0.31, 0.87], dtype=torch.float32)
+        z = torch.from_numpy(tnoise.complex_normal(55, "train_z_" + tag, (2, 1, 512, 64)))
+        start = 1234
+        sd = tw.make_state_dict(1234, **arch)
+        for loss_type in (("mse",) if tag == "a" else ("mse", "mae")):
+            torch.manual_seed(0)
+            m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition=cond, loss_type=loss_type, n_fft=1022,
+                           hop_length=160, num_frames=64, window="hann", sde_input=sde_in).eval()
+            m.score_net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+            o_rand, o_randn, o_unif = torch.rand, torch.randn_like, MW.np.random.uniform
+            torch.rand = lambda *a, **k: (t - m.t_eps) / (m.sde.T - m.t_eps)       # so that rand * (T - eps) + eps == t (to 1 ulp)
+            torch.randn_like = lambda like, **k: z.clone()
+            MW.np.random.uniform = lambda lo, hi: start
+            try:
+                with torch.no_grad():
+                    loss = m.train_step({"clean": clean.clone(), "perturbed": noisy.clone(), "fake": fake.clone()})
+            finally:
+                torch.rand, torch.randn_like, MW.np.random.uniform = o_rand, o_randn, o_unif
+            out[f"loss_{tag}_{loss_type}"] = np.float64(loss.item())
+        out.update({f"clean_{tag}": clean.numpy(), f"noisy_{tag}": noisy.numpy(), f"fake_{tag}": fake.numpy(), f"t_{tag}": t.numpy(),
+                    f"crc_{tag}": tw.weights_checksum(sd)})       # z: tnoise.complex_normal(55, "train_z_<tag>", (2, 1, 512, 64))
+    np.savez(os.path.join(OUT, "train_loss.npz"), start=1234, num_frames=64, weights_seed=1234, z_seed=55, **out)
+
+
 def gen_refine(model=None):
     """LSGAN refine stage: NCSNPP_Wrapper(n_fft=1022, hop=160, num_frames=480) = NCSNpp(discriminative=True)
     between STFT glue (GAN/generator/ncsnpp/model_wrapper.py:19-121, configs/model/LSGAN.yaml:46-53)."""
@@ -316,7 +351,8 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     small = {"fir": gen_fir, "resblocks": gen_resblocks, "attn": gen_attn, "samplers": gen_samplers, "samplers_em": gen_samplers_em,
-             "refine": gen_refine, "forward_small": gen_forward_small, "both": gen_both}
+             "refine": gen_refine, "forward_small": gen_forward_small, "both": gen_both,
+             "train_loss": gen_train_loss}
     big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1,
            "sample_denoised": gen_sample_denoised}
     todo = [a.only] if a.only else list(small) + list(big)

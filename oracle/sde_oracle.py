@@ -198,6 +198,33 @@ def score_model_sample(net_forward: Callable, wav: torch.Tensor, N=50, predictor
     return istft(spec_back(sample.squeeze(1)), T_orig), sample, Y, nfe
 
 
+def score_model_train_loss(net_forward: Callable, clean, perturbed, t, z, start, fake=None, condition="noisy", sde_input="noisy",
+                           num_frames=64, hop=160, loss_type="mse", theta=1.5):
+    """ScoreModel.train_step (model_wrapper.py:147-208) + _loss (:124-133) with the random draws (t [B], complex z, crop start)
+    given: crop / pad to target_len = (num_frames - 1) hop, spectrograms, x_t = mean + std z with OUVESDE.marginal_prob
+    (sdes.py:226-246), err = score(x_t, t) std + z.  ``net_forward(x_c64[B,2 or 3,F,T], t[B])`` is the backbone."""
+    target_len = (num_frames - 1) * hop
+    cur = clean.size(-1)
+    pad = max(target_len - cur, 0)
+    if pad == 0:
+        cut = lambda a: a[..., start:start + target_len]                                  # noqa: E731
+    else:
+        cut = lambda a: torch.nn.functional.pad(a, (pad // 2, pad // 2 + (pad % 2)))       # noqa: E731
+    X = spec_fwd(stft(cut(clean))).unsqueeze(1)
+    Y = spec_fwd(stft(cut(perturbed))).unsqueeze(1)
+    Yd = None if fake is None else spec_fwd(stft(cut(fake))).unsqueeze(1)
+    ysde = Yd if sde_input == "denoised" else Y
+    w = torch.exp(-theta * t)[:, None, None, None]
+    mean = w * X + (1 - w) * ysde                                                          # OUVESDE._mean (sdes.py:226-229)
+    sig = ouve_std(t)[:, None, None, None]
+    xt = mean + sig * z
+    cond = {"noisy": [Y], "denoised": [Yd], "both": [Y, Yd]}[condition]
+    score = -net_forward(torch.cat([xt] + cond, dim=1), t)
+    err = score * sig + z
+    losses = err.abs() ** 2 if loss_type == "mse" else err.abs()
+    return torch.mean(0.5 * torch.sum(losses.reshape(losses.shape[0], -1), dim=-1))
+
+
 def refine_generator(net_forward: Callable, wav: torch.Tensor, n_fft=1022, hop=160):
     """NCSNPP_Wrapper.forward, inference branch (GAN/generator/ncsnpp/model_wrapper.py:114-121): the LSGAN refine stage
     that follows the sampler in the reference's documented pipeline (README.md:175-178; LSGAN_module.py:139-155).

@@ -709,3 +709,33 @@ def test_condition_both_matches_reference(golden_dir, sde_input):
         assert _relmax(o16[key], out[key]) < tol, prec
     with pytest.raises(NotImplementedError):
         m.sample({"perturbed": batch["perturbed"]}, N=1)                    # condition="both" without batch["fake"]
+
+
+@pytest.mark.parametrize("tag,cond,sde_in,arch,losses", [("a", "noisy", "noisy", "LARGE", ("mse",)),
+                                                          ("b", "both", "denoised", "LARGE_BOTH", ("mse", "mae"))])
+def test_train_step_loss_matches_reference(golden_dir, tag, cond, sde_in, arch, losses):
+    """SURVEY 8f4, forward half: ScoreModel.train_step (model_wrapper.py:147-208) -- what the reference module's validation_step /
+    test_step log (SGMSE_module.py:56-63) -- through the HIP score network, against losses computed by the reference with the same
+    t, z and crop start: random-excerpt and zero-padding branches, conditions noisy / both, mse / mae.  fp32: 2e-4 relative;
+    bf16 within 3 % (sum of 65 k squared errors).  Optimisation itself is not served: training_step raises."""
+    from universal_speech_enhancement_amd.SGMSE_module import SGMSEModule
+    from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel
+    g = dict(np.load(os.path.join(golden_dir, "train_loss.npz")))
+    sd = tw.make_state_dict(int(g["weights_seed"]), **getattr(tw, arch))
+    z = torch.from_numpy(tnoise.complex_normal(int(g["z_seed"]), "train_z_" + tag, (2, 1, 512, 64))).cuda()
+    batch = {"clean": torch.from_numpy(g["clean_" + tag]).cuda(), "perturbed": torch.from_numpy(g["noisy_" + tag]).cuda(),
+             "fake": torch.from_numpy(g["fake_" + tag]).cuda()}
+    t = torch.from_numpy(g["t_" + tag]).cuda()
+    for lt in losses:
+        for prec, tol in (("fp32", 2e-4), ("bf16", 3e-2)):
+            m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition=cond, loss_type=lt, n_fft=1022, hop_length=160,
+                           num_frames=int(g["num_frames"]), window="hann", sde_input=sde_in, precision=prec)
+            m.score_net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            loss = m.train_step(batch, t=t, z=z, start=int(g["start"]))
+            want = float(g[f"loss_{tag}_{lt}"])
+            assert abs(float(loss) - want) < tol * want, (lt, prec, float(loss), want)
+    mod = SGMSEModule(Score=m)
+    v = mod.validation_step(batch)                                       # random t, z, start: finite, same order of magnitude
+    assert torch.isfinite(v) and 0.1 * want < float(v) < 10 * want
+    with pytest.raises(NotImplementedError):
+        mod.training_step(batch, 0)

@@ -109,6 +109,25 @@ def test_forward_six_channel_matches_reference(golden_dir):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("tag,cond,sde_in,arch,losses", [("a", "noisy", "noisy", "LARGE", ("mse",)),
+                                                          ("b", "both", "denoised", "LARGE_BOTH", ("mse", "mae"))])
+def test_train_loss_matches_reference(golden_dir, tag, cond, sde_in, arch, losses):
+    """SURVEY 8f4 (forward half): ScoreModel.train_step = the loss validation_step / test_step log, random draws pinned."""
+    g = _load(golden_dir, "train_loss.npz")
+    sd_np = tw.make_state_dict(int(g["weights_seed"]), **getattr(tw, arch))
+    assert tw.weights_checksum(sd_np) == str(g["crc_" + tag])
+    sd = no.to_torch(sd_np)
+    z = torch.from_numpy(tnoise.complex_normal(int(g["z_seed"]), "train_z_" + tag, (2, 1, 512, 64)))
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    for lt in losses:
+        with torch.no_grad():
+            loss = so.score_model_train_loss(lambda x, t: no.ncsnpp_forward(sd, x, t), torch.from_numpy(g["clean_" + tag]),
+                                             torch.from_numpy(g["noisy_" + tag]), torch.from_numpy(g["t_" + tag]), z, int(g["start"]),
+                                             fake=torch.from_numpy(g["fake_" + tag]), condition=cond, sde_input=sde_in,
+                                             num_frames=int(g["num_frames"]), loss_type=lt)
+        assert abs(float(loss) - float(g[f"loss_{tag}_{lt}"])) < 2e-5 * float(g[f"loss_{tag}_{lt}"]), (lt, float(loss))
+
+
 @pytest.mark.slow
 def test_sample_e2e_matches_reference(golden_dir, large_sd):
     g = _load(golden_dir, "sample_e2e.npz")

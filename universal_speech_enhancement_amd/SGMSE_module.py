@@ -53,5 +53,20 @@ class SGMSEModule(torch.nn.Module):
             _write_wav(enhanced_path, wav, sample_rate, self.wav_subtype)
         return batch
 
+    def get_score_loss(self, batch: dict) -> torch.Tensor:
+        """Reference :42-44."""
+        return self.Score.train_step(batch)
+
+    @torch.no_grad()
+    def validation_step(self, batch: dict, batch_idx: int = 0) -> torch.Tensor:
+        """Reference :56-58 (there the value goes to ``self.log("val/loss_Score", ...)``; without Lightning it is returned)."""
+        return self.get_score_loss(batch)
+
+    @torch.no_grad()
+    def test_step(self, batch: dict, batch_idx: int = 0) -> torch.Tensor:
+        """Reference :61-63."""
+        return self.get_score_loss(batch)
+
     def training_step(self, *a, **k):
-        raise NotImplementedError("training is outside the scope of the MI355X sampling library")
+        raise NotImplementedError("optimisation is outside the scope of the MI355X sampling library: there are no backward kernels "
+                                  "(the loss itself is available: validation_step / Score.train_step)")

@@ -46,8 +46,62 @@ class ScoreModel(SpectralGlue, nn.Module):
     def forward(self, x, t, score_conditioning, sde_input):
         return self.forward_score(x, t, score_conditioning, sde_input)
 
-    def train_step(self, batch):
-        raise NotImplementedError("training is outside the scope of the MI355X sampling library (inference only)")
+    def _loss(self, err):
+        """Reference :124-133."""
+        if self.loss_type == "mse":
+            losses = torch.square(err.abs())
+        elif self.loss_type == "mae":
+            losses = err.abs()
+        else:
+            raise NotImplementedError(f"loss_type {self.loss_type!r}")
+        return torch.mean(0.5 * torch.sum(losses.reshape(losses.shape[0], -1), dim=-1))
+
+    @torch.no_grad()
+    def train_step(self, batch, t=None, z=None, start=None):
+        """The denoising-score-matching loss of one batch (reference :147-208): crop / pad to ``target_len``, spectrograms,
+        t ~ U(t_eps, T), x_t = mean(x0, t, y) + std(t) z, err = score(x_t) std + z, ``_loss(err)``.  **Forward only** -- this is
+        what ``validation_step`` / ``test_step`` of the reference module log (SGMSE_module.py:56-63); the library has no backward
+        kernels, so the value carries no gradient and ``SGMSEModule.training_step`` refuses to optimise with it.
+        ``t`` [B], ``z`` complex [B,1,F,T] and ``start`` override the random draws (the reference draws them from the global
+        numpy / torch generators)."""
+        import numpy as np
+        import torch.nn.functional as F
+        x, y = batch["clean"], batch["perturbed"]
+        y_denoised = batch.get("fake")
+        current_len = x.size(-1)
+        pad = max(self.target_len - current_len, 0)
+        if pad == 0:                                                     # a random target_len excerpt
+            if start is None:
+                start = int(np.random.uniform(0, current_len - self.target_len))
+            cut = lambda a: a[..., start:start + self.target_len]       # noqa: E731
+        else:                                                            # centre the short utterance in zeros
+            cut = lambda a: F.pad(a, (pad // 2, pad // 2 + (pad % 2)), mode="constant")   # noqa: E731
+        X, Y = self._spectrogram(cut(x).contiguous()), self._spectrogram(cut(y).contiguous())
+        Yd = None if y_denoised is None else self._spectrogram(cut(y_denoised).contiguous())
+        if self.sde_input == "denoised" and Yd is not None:
+            sde_input = Yd
+        elif self.sde_input == "noisy":
+            sde_input = Y
+        else:
+            raise NotImplementedError(f"Don't know the sde input you have wished for: {self.sde_input}")
+        if t is None:
+            t = torch.rand(X.shape[0], device=X.device) * (self.sde.T - self.t_eps) + self.t_eps
+        t = t.to(device=X.device, dtype=torch.float32)
+        mean, std = self.sde.marginal_prob(X, t, sde_input)
+        if z is None:
+            z = torch.randn_like(X)                                      # complex: variance 1/2 per component
+        sigmas = std.view(-1, 1, 1, 1)
+        perturbed = mean + sigmas * z
+        if self.condition == "noisy":
+            score_conditioning = [Y]
+        elif self.condition == "denoised" and Yd is not None:
+            score_conditioning = [Yd]
+        elif self.condition == "both" and Yd is not None:
+            score_conditioning = [Y, Yd]
+        else:
+            raise NotImplementedError(f"Don't know the conditioning you have wished for: {self.condition}")
+        score = self.forward_score(perturbed, t, score_conditioning, sde_input)
+        return self._loss(score * sigmas + z)
 
     # ---- samplers (reference :210-260) -------------------------------------------------------------------
     def fused_sample(self, y, N, predictor, corrector, corrector_steps, snr, t_eps, noise=None, seed=0, use_graph=True,
