@@ -217,6 +217,25 @@ def test_intermediate_taps_match_oracle_fp32(golden_dir, engines, sd_np):
         assert _relmax(got, taps[name]) < 5e-4, name
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_input_convolution_16bit_modes_match_the_oracle(golden_dir, engines, sd_np, prec):
+    """conv_in_split_kernel (16-bit storage modes: the fp32 input convolution as a split-bf16 contraction, x w = xh wh + xh wl +
+    xl wh) against the CPU oracle's fp32 convolution of the same input: the only difference allowed is the rounding of the stored
+    output (bf16: 2^-9, fp16: 2^-12 relative) plus the dropped 2^-16 term."""
+    g = dict(np.load(os.path.join(golden_dir, "forward_large.npz")))
+    x = torch.from_numpy(g["x"]); t = torch.from_numpy(g["t_b"])
+    taps = {}
+    with torch.no_grad():
+        no.ncsnpp_forward(no.to_torch(sd_np), x, t, taps=taps)
+    xc = x.cuda()
+    engines[prec].score(xc[:, 0:1].contiguous(), xc[:, 1:2].contiguous(), t.cuda())
+    got = engines[prec].debug_tensor("h_in").permute(0, 3, 1, 2).cpu()
+    want = taps["h_in"]
+    ulp = 2.0 ** -8 if prec == "bf16" else 2.0 ** -11
+    err = (got - want).abs()
+    assert float((err - (ulp * want.abs() + 2e-4)).max()) <= 0, float(err.max())
+
+
 def test_backbone_interface_returns_network_output(golden_dir, sd_np):
     from universal_speech_enhancement_amd.sgmse.backbones import BackboneRegistry
     g = dict(np.load(os.path.join(golden_dir, "forward_large.npz")))

@@ -73,7 +73,8 @@ static inline uint16_t f32_to_f16(float f) {    // round to nearest even, overfl
 struct ConvW { std::string wname, bname; int cin = 0, cout = 0, cout_pad = 0, ntaps = 1, w_dtype = DT_F32;
                bool nin = false; size_t w_off = 0, b_off = 0;
                int cin_src = 0, cout_src = 0;                 // extents of the host tensor when it is zero-padded to cin / cout
-               size_t wb_off = 0; bool has_wb = false; };     // slab-major copy for conv_v4_kernel (see pack_conv)
+               size_t wb_off = 0; bool has_wb = false;        // slab-major copy for conv_v4_kernel (see pack_conv)
+               bool split_in = false; };                      // wb = the bf16 hi / lo split copy of the input convolution (pack_conv_in_split)
 struct GNW { std::string prefix; int C = 0; size_t g_off = 0, b_off = 0; };
 struct ResW { int idx = 0, in_ch = 0, out_ch = 0; bool up = false, down = false, has_c2 = false;
               GNW gn0, gn1; ConvW c0, c1, c2; int dense_row0 = 0; size_t b12_off = 0; };   // b12 = Conv_1.bias + Conv_2.bias
@@ -280,13 +281,21 @@ static int build_arch(use_handle* h) {
         w.has_wb = !w.nin && w.cout_pad % 128 == 0 && w.cin % conv_v4_chunk(w.w_dtype) == 0 && (w.ntaps == 9 || w.ntaps == 1);
         if (w.has_wb) w.wb_off = take((size_t)w.ntaps * w.cout_pad * w.cin * dtype_size(w.w_dtype));
     };
+    // the input convolution in the 16-bit modes: split-bf16 copy [cout_pad][CONV_IN_SPLIT_K] for conv_in_split_kernel
+    auto lay_conv_in = [&](ConvW& w) {
+        lay_conv(w);
+        if (dt != DT_F32 && w.cin == 4 && w.ntaps == 9 && w.cout_pad % 128 == 0) {
+            w.split_in = true; w.has_wb = true;
+            w.wb_off = take((size_t)w.cout_pad * CONV_IN_SPLIT_K * 2);
+        }
+    };
     auto lay_gn = [&](GNW& g) { g.g_off = take((size_t)g.C * 4); g.b_off = take((size_t)g.C * 4); };
     h->outw_off = take((size_t)2 * pcp * 4); h->outb_off = take(2 * 4);
     h->gfp_off = take((size_t)nf * 4);
     h->l1w_off = take((size_t)4 * nf * 2 * nf * 4); h->l1b_off = take((size_t)4 * nf * 4);
     h->l2w_off = take((size_t)4 * nf * 4 * nf * 4); h->l2b_off = take((size_t)4 * nf * 4);
     h->dense_w_off = take((size_t)h->dense_rows * 4 * nf * 4); h->dense_b_off = take((size_t)h->dense_rows * 4);
-    lay_conv(h->conv_in);
+    lay_conv_in(h->conv_in);
     for (auto& r : h->res) {
         lay_gn(r.gn0); lay_conv(r.c0); lay_gn(r.gn1); lay_conv(r.c1);
         if (r.has_c2) { lay_conv(r.c2); r.b12_off = take((size_t)r.out_ch * 4); }
@@ -329,9 +338,27 @@ static void pack_conv_raw(const float* src, const ConvW& w, char* dst, char* dst
                 }
     }
 }
+// Input convolution, 16-bit modes: w = wh + wl with wh = bf16(w), wl = bf16(w - wh); row n of the copy holds the K = 112 operand
+// of conv_in_split_kernel: k = 4 u + ci, unit u = (block, tap): block 0 -> wh (meets xh), block 1 -> wl (meets xh), block 2 -> wh
+// (meets xl), unit 27 = zero padding.  x w = xh wh + xh wl + xl wh + O(2^-16 |x w|).
+static void pack_conv_in_split(const float* src, const ConvW& w, char* dst) {
+    uint16_t* d = (uint16_t*)dst;
+    memset(dst, 0, (size_t)w.cout_pad * CONV_IN_SPLIT_K * 2);
+    for (int co = 0; co < w.cout_src; ++co)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ci = 0; ci < w.cin_src; ++ci) {
+                const float v = src[((size_t)co * w.cin_src + ci) * 9 + tap];     // reference conv weight [cout][cin][kh][kw]
+                const uint16_t hi = f32_to_bf16(v);
+                uint32_t hb = (uint32_t)hi << 16; float hf; memcpy(&hf, &hb, 4);
+                const uint16_t lo = f32_to_bf16(v - hf);
+                uint16_t* row = d + (size_t)co * CONV_IN_SPLIT_K;
+                row[(0 * 9 + tap) * 4 + ci] = hi; row[(1 * 9 + tap) * 4 + ci] = lo; row[(2 * 9 + tap) * 4 + ci] = hi;
+            }
+}
 static void pack_conv(const use_handle* h, const ConvW& w, char* blob) {
     const std::vector<float>& bias = h->host_w.at(w.bname);
-    pack_conv_raw(h->host_w.at(w.wname).data(), w, blob + w.w_off, w.has_wb ? blob + w.wb_off : nullptr);
+    pack_conv_raw(h->host_w.at(w.wname).data(), w, blob + w.w_off, (w.has_wb && !w.split_in) ? blob + w.wb_off : nullptr);
+    if (w.split_in) pack_conv_in_split(h->host_w.at(w.wname).data(), w, blob + w.wb_off);
     memset(blob + w.b_off, 0, (size_t)w.cout * 4);
     memcpy(blob + w.b_off, bias.data(), (size_t)w.cout_src * 4);
 }
@@ -880,7 +907,7 @@ int use_commit_weights(use_handle* h) {
 // ---- packed weight file: header + the device blob, so that a deployment starts without a state dict ------
 // The blob layout is private to a library build: BLOB_LAYOUT is bumped whenever pack_all / the blob offsets change.
 namespace {
-constexpr uint32_t BLOB_LAYOUT = 4;          // 4: slab-major copy of the 3x3 / shortcut weights with piece-swizzled 64-byte rows
+constexpr uint32_t BLOB_LAYOUT = 5;          // 5: + split-bf16 copy of the input convolution (16-bit modes); 4: piece-swizzled slab copies
 struct BlobHeader {
     char magic[8];                           // "USEHIPWB"
     uint32_t header_bytes, layout;

@@ -9,6 +9,7 @@ namespace use {
 enum DType { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 
+constexpr int CONV_IN_SPLIT_K = 112;   // K of conv_in_split_kernel: 3 blocks (hi*hi, hi*lo, lo*hi) x 9 taps x 4 channels, padded to 7 x 16
 constexpr int TILE_H = 8;    // conv output tile: 8 x 16 pixels = 128 GEMM rows
 constexpr int TILE_W = 16;
 

@@ -542,6 +542,149 @@ __global__ __launch_bounds__(256) void conv_in_kernel(ConvArgs p) {
         }
     }
 }
+// conv_in_split_kernel: the same layer in the 16-bit storage modes.  The fp32 MFMA runs at the fp32 vector rate (157 TF/s: 77 us of
+// arithmetic at 512x640 before anything else), 16x below the bf16 pipe -- and the layer's job is to write 335 MB.  So the fp32
+// operands are split into bf16 pairs, x = xh + xl, w = wh + wl (hi = bf16(v), lo = bf16(v - hi)), and
+//   x w = xh wh + xh wl + xl wh            (the dropped xl wl term is 2^-16 relative: 250x below the bf16 rounding of the output)
+// runs as ONE K = 3 x 36 (+4 zero) = 112 contraction on v_mfma_f32_32x32x16_bf16: 7 MFMAs per 32x32 output tile instead of 18
+// fp32 ones at a quarter of the cycles each.  fp32 accumulation; output rounding / GroupNorm totals as in conv_in_kernel.  The
+// weight operand comes pre-split from the blob (ConvArgs::wb, pack_conv_in_split); the fp32 parity mode keeps conv_in_kernel.
+constexpr int CINS_WP = CONV_IN_SPLIT_K * 2 + 16;            // weight row pitch in LDS (bytes): 240 = 15 x 16, conflict-free b128 reads
+constexpr int CINS_XB = (TILE_H + 2) * (TILE_W + 2) * 8;     // one halo array: [180 px][4] bf16
+constexpr int CINS_SP = 72;                                  // staging row pitch (floats) of a 32-pixel x 64-channel half tile
+// A workgroup walks `tiles_per_wg` consecutive tiles of one item: the weights are staged once, and the GroupNorm totals leave as ONE
+// pair of atomics per channel per workgroup -- with a workgroup per tile the 2560 tiles of a 512x640 map queue 2560 deep on each of
+// the item's 256 totals, and that queue, not the arithmetic or the stores, set the kernel's duration (326 us).
+template <typename TOUT>
+__global__ __launch_bounds__(256) void conv_in_split_kernel(ConvArgs p, int tiles_per_wg) {
+    static_assert(sizeof(TOUT) == 2, "16-bit storage modes only");
+    constexpr int HALO = (TILE_H + 2) * (TILE_W + 2);
+    __shared__ __attribute__((aligned(16))) char s_x[3 * CINS_XB];           // [xh | xl | zeros], each [180][4] bf16
+    __shared__ __attribute__((aligned(16))) char s_w[128 * CINS_WP];         // [128 co][112 (+8)] bf16
+    __shared__ __attribute__((aligned(16))) float s_stg[4 * 32 * CINS_SP];   // per wave: [32 px][64 (+8)] fp32
+    __shared__ float s_red[4 * 128 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    const int tiles_x = (p.W + TILE_W - 1) / TILE_W, ntiles = tiles_x * ((p.H + TILE_H - 1) / TILE_H);
+    const int n0 = blockIdx.y * 128;
+    const float* src = (const float*)p.src0;
+    {
+        const char* wsrc = (const char*)p.wb + (size_t)n0 * (CONV_IN_SPLIT_K * 2);      // [CoutPad][112] bf16, rows of 224 bytes
+        for (int i = tid; i < 128 * 14; i += 256) {
+            const int row = i / 14, pc = i - row * 14;
+            *reinterpret_cast<uint4*>(s_w + row * CINS_WP + pc * 16) = *reinterpret_cast<const uint4*>(wsrc + (size_t)row * (CONV_IN_SPLIT_K * 2) + pc * 16);
+        }
+        for (int i = tid; i < HALO; i += 256) *reinterpret_cast<uint2*>(s_x + 2 * CINS_XB + i * 8) = make_uint2(0u, 0u);
+    }
+    const int m = lane & 31, hlf = lane >> 5;
+    const char* const pa = s_x + ((wave * 2 + (m >> 4)) * (TILE_W + 2) + (m & 15)) * 8;
+    const char* const pb = s_w + m * CINS_WP + hlf * 16;
+    float* const stg = s_stg + wave * (32 * CINS_SP);
+    constexpr int CH = 8, CPR = 8, PPQ = 8;                   // 16-byte chunks: 8 channels; 8 chunks per half-tile row; 8 pixels per pass
+    const int ch = lane % CPR;
+    float bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int co = n0 + j * 32 + m; bias[j] = (co < p.Cout && p.bias) ? p.bias[co] : 0.f; }
+    float st_s[2][CH], st_q[2][CH];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { st_s[h2][c] = 0.f; st_q[h2][c] = 0.f; }
+    TOUT* out = (TOUT*)p.out;
+    const int t_end = min(ntiles, ((int)blockIdx.x + 1) * tiles_per_wg);
+    for (int tile = blockIdx.x * tiles_per_wg; tile < t_end; ++tile) {
+        const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
+        for (int i = tid; i < HALO; i += 256) {
+            const int hy = i / (TILE_W + 2), hx = i - hy * (TILE_W + 2);
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = *reinterpret_cast<const float4*>(src + ((size_t)(b * p.H + gy) * p.W + gx) * 4);
+            const float xs[4] = {v.x, v.y, v.z, v.w};
+            __bf16 hi[4], lo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { hi[c] = (__bf16)xs[c]; lo[c] = (__bf16)(xs[c] - (float)hi[c]); }
+            *reinterpret_cast<uint2*>(s_x + i * 8) = *reinterpret_cast<const uint2*>(hi);
+            *reinterpret_cast<uint2*>(s_x + CINS_XB + i * 8) = *reinterpret_cast<const uint2*>(lo);
+        }
+        __syncthreads();
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = bias[j];
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            // this lane's 8 k of the step = units 4 s + 2 hlf + {0, 1}; unit u -> (block u / 9: xh, xh, xl; u = 27: zeros), tap u % 9
+            uint2 a2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int u0 = 4 * s + e, u1 = 4 * s + 2 + e;                      // hlf = 0 / 1 (both compile-time)
+                const int o0 = (u0 < 18 ? 0 : u0 < 27 ? 1 : 2) * CINS_XB + (u0 < 27 ? (((u0 % 9) / 3) * (TILE_W + 2) + (u0 % 9) % 3) * 8 : 0);
+                const int o1 = (u1 < 18 ? 0 : u1 < 27 ? 1 : 2) * CINS_XB + (u1 < 27 ? (((u1 % 9) / 3) * (TILE_W + 2) + (u1 % 9) % 3) * 8 : 0);
+                a2[e] = *reinterpret_cast<const uint2*>(pa + (hlf ? o1 : o0));
+            }
+            const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(a2[0].x, a2[0].y, a2[1].x, a2[1].y));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<const bf16x8*>(pb + j * 32 * CINS_WP + s * 32), acc[j], 0, 0, 0);
+        }
+        // epilogue, per wave, 64 channels at a time through its own staging: 16-byte stores, 128 contiguous bytes per pixel
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    stg[row * CINS_SP + jj * 32 + m] = acc[h2 * 2 + jj][r] * p.out_scale;
+                }
+            __builtin_amdgcn_wave_barrier();
+            const int co0 = n0 + h2 * 64 + ch * CH;
+#pragma unroll
+            for (int q = 0; q < 32 / PPQ; ++q) {
+                const int row = q * PPQ + lane / CPR;
+                const int gy = ty0 + wave * 2 + (row >> 4), gx = tx0 + (row & 15);
+                if (co0 < p.Cout && gy < p.H && gx < p.W) {
+                    float v[CH];
+#pragma unroll
+                    for (int c4 = 0; c4 < CH / 4; ++c4) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(stg + row * CINS_SP + ch * CH + c4 * 4);
+                        v[c4 * 4] = t4.x; v[c4 * 4 + 1] = t4.y; v[c4 * 4 + 2] = t4.z; v[c4 * 4 + 3] = t4.w;
+                    }
+                    const uint4 packed = Vec16<TOUT>::pack(v);
+                    *reinterpret_cast<uint4*>(out + ((size_t)(b * p.H + gy) * p.W + gx) * p.Cout + co0) = packed;
+                    float vr[CH];
+                    Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&packed), vr);       // statistics of the stored values
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) { st_s[h2][c] += vr[c]; st_q[h2][c] += vr[c] * vr[c]; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();                                     // every wave is done with this tile's halo
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { st_s[h2][c] = reduce_lanes_stride<CPR>(st_s[h2][c]); st_q[h2][c] = reduce_lanes_stride<CPR>(st_q[h2][c]); }
+            if (lane < CPR) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    s_red[(wave * 128 + h2 * 64 + ch * CH + c) * 2] = st_s[h2][c]; s_red[(wave * 128 + h2 * 64 + ch * CH + c) * 2 + 1] = st_q[h2][c];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float sm = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { sm += s_red[(w * 128 + tid) * 2]; q += s_red[(w * 128 + tid) * 2 + 1]; }
+            const int co = n0 + tid;
+            if (co < p.Cout) gn_accumulate(p.stats + ((size_t)b * p.Cout + co) * 2, sm, q);
+        }
+    }
+}
 static bool conv_in_eligible(const ConvArgs& a) {
     return a.in_dtype == DT_F32 && a.C0 == 4 && a.C1 == 0 && a.ntaps == 9 && !a.coef && !a.act && !a.res && !a.pyr && !a.temb &&
            a.XC0 + a.XC1 == 0 && a.Cout % 8 == 0;
@@ -585,8 +728,12 @@ void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
     }
     if (conv_in_eligible(a)) {
         dim3 grid(tiles_per_image(a.H, a.W), (a.Cout + 127) / 128, a.B);
-        if (a.out_dtype == DT_BF16)     hipLaunchKernelGGL((conv_in_kernel<__bf16>), grid, dim3(256), 0, s, a);
-        else if (a.out_dtype == DT_F16) hipLaunchKernelGGL((conv_in_kernel<_Float16>), grid, dim3(256), 0, s, a);
+        const int ntiles = tiles_per_image(a.H, a.W), tpw = (ntiles + 255) / 256;       // <= 256 workgroups per item
+        dim3 grid_s((ntiles + tpw - 1) / tpw, (a.Cout + 127) / 128, a.B);
+        if (a.out_dtype == DT_BF16)     { if (a.wb) hipLaunchKernelGGL((conv_in_split_kernel<__bf16>), grid_s, dim3(256), 0, s, a, tpw);
+                                          else      hipLaunchKernelGGL((conv_in_kernel<__bf16>), grid, dim3(256), 0, s, a); }
+        else if (a.out_dtype == DT_F16) { if (a.wb) hipLaunchKernelGGL((conv_in_split_kernel<_Float16>), grid_s, dim3(256), 0, s, a, tpw);
+                                          else      hipLaunchKernelGGL((conv_in_kernel<_Float16>), grid, dim3(256), 0, s, a); }
         else                            hipLaunchKernelGGL((conv_in_kernel<float>), grid, dim3(256), 0, s, a);
         return;
     }
