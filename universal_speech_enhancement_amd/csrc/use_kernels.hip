@@ -312,8 +312,12 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
 // activated halo of 128 input channels (51 KB) and the 4 weight rows of all 9 taps are staged once per 128-channel block,
 // then each wave runs 72 MFMAs (32 pixels x [4 of 32] channels x K = 9 x 128) with no barrier in between.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int PYR_CB = 128;                                  // input channels per staged block
-constexpr int PYR_ROWB = PYR_CB * 2 + 16;                    // 272: pixel row pitch in LDS
+#ifndef USE_PYR_CB
+#define USE_PYR_CB 128
+#endif
+constexpr int PYR_CB = USE_PYR_CB;                           // input channels per staged block
+constexpr int PYR_PP = PYR_CB / 8;                           // 16-byte pieces per pixel of a block
+constexpr int PYR_ROWB = PYR_CB * 2 + 16;                    // 272 (144): pixel row pitch in LDS
 constexpr int PYR_HPITCH = ((TILE_W + 2) * PYR_ROWB + 255) / 256 * 256;      // halo row pitch: multiple of 256 B (see conv_v2)
 constexpr int PYR_HALO = (TILE_H + 2) * PYR_HPITCH;
 constexpr int PYR_WB = 9 * 4 * PYR_ROWB;
@@ -330,14 +334,14 @@ __global__ __launch_bounds__(256) void pyr_conv_kernel(ConvArgs p) {
     const int ty0 = (blockIdx.x / tiles_x) * TILE_H, tx0 = (blockIdx.x % tiles_x) * TILE_W;
     const int Cin = p.C0;
     const T16* src = (const T16*)p.src0;
-    const int part = tid & 15;                               // this thread's 8 channels of every 128-channel block
+    const int part = tid % PYR_PP;                           // this thread's 8 channels of every block
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int m = lane & 31;
     const int a_base = (wave * 2 + (m >> 4)) * PYR_HPITCH + (m & 15) * PYR_ROWB + (lane >> 5) * 16;
     const int b_base = (lane & 3) * PYR_ROWB + (lane >> 5) * 16;           // output channels >= 4 are never stored
-    constexpr int NP = ((TILE_H + 2) * (TILE_W + 2) * 16 + 255) / 256;      // 12 halo pieces per thread
+    constexpr int NP = ((TILE_H + 2) * (TILE_W + 2) * PYR_PP + 255) / 256;  // halo pieces per thread
     for (int c0 = 0; c0 < Cin; c0 += PYR_CB) {
         if (c0) __syncthreads();                             // every wave is done with the previous block
         float ca[8], cb[8];
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256) void pyr_conv_kernel(ConvArgs p) {
         uint4 raw[NP]; int dst[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int idx = j * 256 + tid, pix = idx >> 4;
+            const int idx = j * 256 + tid, pix = idx / PYR_PP;
             const int hy = pix / (TILE_W + 2), hx = pix - hy * (TILE_W + 2);
             const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
             const bool have = pix < (TILE_H + 2) * (TILE_W + 2);
@@ -366,8 +370,8 @@ __global__ __launch_bounds__(256) void pyr_conv_kernel(ConvArgs p) {
             raw[j] = inb ? *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.H + gy) * p.W + gx) * Cin + c0 + part * 8)
                          : make_uint4(0, 0, 0, 0);
         }
-        for (int i = tid; i < 9 * 4 * 16; i += 256) {        // weight rows 0..3: packed [CoutPad][9][Cin]
-            const int pc = i & 15, row = i >> 4;             // row = tap * 4 + co
+        for (int i = tid; i < 9 * 4 * PYR_PP; i += 256) {    // weight rows 0..3: packed [CoutPad][9][Cin]
+            const int pc = i % PYR_PP, row = i / PYR_PP;     // row = tap * 4 + co
             const int tap = row >> 2, co = row & 3;
             *reinterpret_cast<uint4*>(s_w + row * PYR_ROWB + pc * 16) =
                 *reinterpret_cast<const uint4*>((const T16*)p.w + ((size_t)co * 9 + tap) * Cin + c0 + pc * 8);
