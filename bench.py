@@ -35,16 +35,7 @@ PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.
 PEAK_FP32_TFLOPS = 157.3
 
 
-def usable_cores():
-    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(float(quota) / float(period))))
-    except Exception:
-        pass
-    return max(1, n)
+from universal_speech_enhancement_amd.testing.cpu import usable_cores  # noqa: E402
 
 
 def cpu_baseline(sd_np):

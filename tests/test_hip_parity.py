@@ -19,6 +19,7 @@ from oracle import sde_oracle as so
 from universal_speech_enhancement_amd._lib import UseHipError
 from universal_speech_enhancement_amd.testing import noise as tnoise
 from universal_speech_enhancement_amd.testing import weights as tw
+from universal_speech_enhancement_amd.testing.cpu import usable_cores
 
 pytestmark = pytest.mark.gpu
 
@@ -507,7 +508,7 @@ def test_cfg2_shape_score_fp32_matches_oracle(sd_np):
     assert torch.equal(out[0], out[2]) and torch.equal(out[0], out[6]) and torch.equal(out[1], out[4]), \
         "an item's result must not depend on its position in the batch / sub-batch"
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
-    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    torch.set_num_threads(usable_cores())
     with torch.no_grad():
         ref = no.ncsnpp_forward(sd, torch.cat([x2, y2], dim=1), t2)
     for i in (0, 1):

@@ -10,6 +10,7 @@ from oracle import ncsnpp_oracle as no
 from oracle import sde_oracle as so
 from universal_speech_enhancement_amd.testing import noise as tnoise
 from universal_speech_enhancement_amd.testing import weights as tw
+from universal_speech_enhancement_amd.testing.cpu import usable_cores
 
 TOL = dict(rtol=1e-5, atol=1e-5)
 
@@ -87,7 +88,7 @@ def test_forward_large_matches_reference(golden_dir, large_sd):
     g = _load(golden_dir, "forward_large.npz")
     sd = large_sd[0]
     x = torch.from_numpy(g["x"])
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(usable_cores())
     with torch.no_grad():
         for tag in ("a", "b"):
             out = no.ncsnpp_forward(sd, x, torch.from_numpy(g["t_" + tag]))
@@ -102,7 +103,7 @@ def test_forward_six_channel_matches_reference(golden_dir):
     sd_np = tw.make_state_dict(1234, **tw.LARGE_BOTH)
     assert str(g["weights_crc"]) == tw.weights_checksum(sd_np)
     assert sd_np["output_layer.weight"].shape == (2, 6, 1, 1) and sd_np["all_modules.3.weight"].shape == (128, 6, 3, 3)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(usable_cores())
     with torch.no_grad():
         out = no.ncsnpp_forward(no.to_torch(sd_np), torch.from_numpy(g["x"]), torch.from_numpy(g["t"]))
     err = np.abs(out.numpy() - g["fwd"]).max() / np.abs(g["fwd"]).max()
@@ -118,7 +119,7 @@ def test_train_loss_matches_reference(golden_dir, tag, cond, sde_in, arch, losse
     assert tw.weights_checksum(sd_np) == str(g["crc_" + tag])
     sd = no.to_torch(sd_np)
     z = torch.from_numpy(tnoise.complex_normal(int(g["z_seed"]), "train_z_" + tag, (2, 1, 512, 64)))
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(usable_cores())
     for lt in losses:
         with torch.no_grad():
             loss = so.score_model_train_loss(lambda x, t: no.ncsnpp_forward(sd, x, t), torch.from_numpy(g["clean_" + tag]),
@@ -152,7 +153,7 @@ def test_refine_generator_matches_reference(golden_dir):
     assert str(g["weights_crc"]) == tw.weights_checksum(sd_np)
     sd = no.to_torch(sd_np)
     net = lambda Y: no.ncsnpp_forward(sd, Y, None, ch_mult=tw.REFINE["ch_mult"], num_res_blocks=1, discriminative=True)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(usable_cores())
     with torch.no_grad():
         out = net(torch.from_numpy(g["x"]))
         fake, _, _ = so.refine_generator(net, torch.from_numpy(g["wav"]))
@@ -168,7 +169,7 @@ def test_small_variants_match_reference(golden_dir, name, arch):
     sd_np = tw.make_state_dict(int(g["weights_seed"]), **arch)
     assert str(g["weights_crc"]) == tw.weights_checksum(sd_np)
     x = torch.from_numpy(tnoise.complex_normal(int(g["x_seed"]), "small_x", (2, 2, 512, 64))) * 0.5
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(usable_cores())
     with torch.no_grad():
         out = no.ncsnpp_forward(no.to_torch(sd_np), x, torch.from_numpy(g["t"]), ch_mult=arch["ch_mult"], num_res_blocks=arch["num_res_blocks"])
     err = np.abs(out.numpy() - g["out"]).max() / np.abs(g["out"]).max()
