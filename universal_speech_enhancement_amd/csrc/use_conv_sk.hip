@@ -266,18 +266,22 @@ __global__ __launch_bounds__(512) void conv_sk_kernel(ConvArgs p, int TH, int TW
     const int ch = tid % CPR;
     const int co0 = n0 + ch * CH;
     float addv[CH], st_s[CH], st_q[CH];
+    const int nvalid = p.Cout - co0;                             // channels of this chunk that exist (Cout < NT: the 4- / 8-channel
+                                                                 // pyramid convolutions, whose weight rows are zero-padded to 32)
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         float add = 0.f;
-        if (p.bias) add += p.bias[co0 + c];
-        if (p.temb) add += p.temb[(size_t)b * p.temb_bstride + co0 + c];
+        if (c < nvalid) {
+            if (p.bias) add += p.bias[co0 + c];
+            if (p.temb) add += p.temb[(size_t)b * p.temb_bstride + co0 + c];
+        }
         addv[c] = add; st_s[c] = 0.f; st_q[c] = 0.f;
     }
 #pragma unroll
     for (int it0 = 0; it0 < ITEMS; it0 += 512) {
         const int it = it0 + tid;
         const int row = it / CPR;
-        if (it < ITEMS && row < TH * TW) {
+        if (it < ITEMS && row < TH * TW && nvalid > 0) {
             const int ty = row / TW, gy = ty0 + ty, gx = tx0 + row - ty * TW;
             if (gy < p.H && gx < p.W) {
                 float v[CH];
@@ -293,13 +297,17 @@ __global__ __launch_bounds__(512) void conv_sk_kernel(ConvArgs p, int TH, int TW
                 const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
                 if (res) {
                     float rv[CH];
-                    Vec16<TOUT>::load(res + pix * p.Cout + co0, rv);
+                    if (nvalid >= CH) Vec16<TOUT>::load(res + pix * p.Cout + co0, rv);
+                    else {
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) rv[c] = c < nvalid ? to_f(res[pix * p.Cout + co0 + c]) : 0.f;
+                    }
 #pragma unroll
                     for (int c = 0; c < CH; ++c) v[c] += rv[c];
                 }
 #pragma unroll
                 for (int c = 0; c < CH; ++c) v[c] *= p.out_scale;
-                if (p.pyr) {
+                if (p.pyr && nvalid >= CH) {
                     const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
@@ -308,7 +316,11 @@ __global__ __launch_bounds__(512) void conv_sk_kernel(ConvArgs p, int TH, int TW
                     }
                 }
                 const uint4 packed = Vec16<TOUT>::pack(v);
-                *reinterpret_cast<uint4*>(out + pix * p.Cout + co0) = packed;
+                if (nvalid >= CH) *reinterpret_cast<uint4*>(out + pix * p.Cout + co0) = packed;
+                else {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) if (c < nvalid) out[pix * p.Cout + co0 + c] = reinterpret_cast<const TOUT*>(&packed)[c];
+                }
                 float vr[CH];
                 Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&packed), vr);   // statistics of the stored values
 #pragma unroll
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(512) void conv_sk_kernel(ConvArgs p, int TH, int TW
             float ss = 0.f, qq = 0.f;
 #pragma unroll
             for (int w = 0; w < NWV; ++w) { const float2 t = st_red[w][tid]; ss += t.x; qq += t.y; }
-            gn_accumulate(p.stats + ((size_t)b * p.Cout + n0 + tid) * 2, ss, qq);
+            if (n0 + tid < p.Cout) gn_accumulate(p.stats + ((size_t)b * p.Cout + n0 + tid) * 2, ss, qq);
         }
     }
 }
@@ -352,10 +364,10 @@ void sk_tile(int H, int W, int pad, int* th, int* tw) {
     *th = bh; *tw = bw;
 }
 
-template <typename T, int NJ, int CP>
+template <typename T, typename TO, int NJ, int CP>
 void sk_launch(const ConvArgs& a, int th, int tw, hipStream_t s) {
     const int tiles = ((a.H + th - 1) / th) * ((a.W + tw - 1) / tw);
-    hipLaunchKernelGGL((conv_sk_kernel<T, T, NJ, CP>), dim3(tiles, a.Cout / (32 * NJ), a.B), dim3(512), 0, s, a, th, tw);
+    hipLaunchKernelGGL((conv_sk_kernel<T, TO, NJ, CP>), dim3(tiles, (a.Cout + 32 * NJ - 1) / (32 * NJ), a.B), dim3(512), 0, s, a, th, tw);
 }
 
 }  // namespace
@@ -364,9 +376,11 @@ void conv_sk_set_max_px(long n) { g_sk_max_px = n; }
 
 bool conv_sk_eligible(const ConvArgs& a) {
     const int Ctot = a.C0 + a.C1, XC = a.XC0 + a.XC1;
-    return (long)a.H * a.W <= g_sk_max_px && (a.ntaps == 9 || a.ntaps == 1) && a.in_dtype == a.out_dtype && a.w &&
-           Ctot % 32 == 0 && a.C0 % 32 == 0 && XC % 32 == 0 && a.XC0 % 32 == 0 && (XC == 0 || a.w2) && Ctot >= 32 && Ctot <= 1024 &&
-           a.Cout % 32 == 0 && a.Cout >= 32;
+    // outputs: full 32-channel tiles in the input's type, or the 4- / 8-channel fp32 pyramid heads (weight rows padded to 32)
+    const bool full = a.in_dtype == a.out_dtype && a.Cout % 32 == 0 && a.Cout >= 32;
+    const bool head = a.out_dtype == DT_F32 && a.Cout <= 8 && a.cout_pad >= 32 && !a.pyr && !a.stats;
+    return (long)a.H * a.W <= g_sk_max_px && (a.ntaps == 9 || a.ntaps == 1) && a.w && (full || head) &&
+           Ctot % 32 == 0 && a.C0 % 32 == 0 && XC % 32 == 0 && a.XC0 % 32 == 0 && (XC == 0 || a.w2) && Ctot >= 32 && Ctot <= 1024;
 }
 
 void launch_conv_sk(const ConvArgs& a, hipStream_t s) {
@@ -375,9 +389,13 @@ void launch_conv_sk(const ConvArgs& a, hipStream_t s) {
     const long tiles = (long)((a.H + th - 1) / th) * ((a.W + tw - 1) / tw) * a.B;
     // 64-channel tiles once 32-channel ones would give more than two workgroups per CU (the halo staging is repeated per channel tile)
     const bool wide = a.Cout % 64 == 0 && tiles * (a.Cout / 32) > 512;
-    if (a.in_dtype == DT_BF16)     { wide ? sk_launch<__bf16, 2, 128>(a, th, tw, s) : sk_launch<__bf16, 1, 256>(a, th, tw, s); }
-    else if (a.in_dtype == DT_F16) { wide ? sk_launch<_Float16, 2, 128>(a, th, tw, s) : sk_launch<_Float16, 1, 256>(a, th, tw, s); }
-    else                           { wide ? sk_launch<float, 2, 64>(a, th, tw, s) : sk_launch<float, 1, 128>(a, th, tw, s); }
+    if (a.in_dtype != a.out_dtype) {                             // pyramid heads of the 16-bit modes: fp32 out
+        if (a.in_dtype == DT_BF16) sk_launch<__bf16, float, 1, 256>(a, th, tw, s); else sk_launch<_Float16, float, 1, 256>(a, th, tw, s);
+        return;
+    }
+    if (a.in_dtype == DT_BF16)     { wide ? sk_launch<__bf16, __bf16, 2, 128>(a, th, tw, s) : sk_launch<__bf16, __bf16, 1, 256>(a, th, tw, s); }
+    else if (a.in_dtype == DT_F16) { wide ? sk_launch<_Float16, _Float16, 2, 128>(a, th, tw, s) : sk_launch<_Float16, _Float16, 1, 256>(a, th, tw, s); }
+    else                           { wide ? sk_launch<float, float, 2, 64>(a, th, tw, s) : sk_launch<float, float, 1, 128>(a, th, tw, s); }
 }
 
 }  // namespace use
