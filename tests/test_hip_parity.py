@@ -759,3 +759,19 @@ def test_train_step_loss_matches_reference(golden_dir, tag, cond, sde_in, arch, 
     assert torch.isfinite(v) and 0.1 * want < float(v) < 10 * want
     with pytest.raises(NotImplementedError):
         mod.training_step(batch, 0)
+
+
+def test_replanning_between_shapes_is_transparent(sd_np):
+    """A predict run over files of different lengths re-plans the workspace and re-captures the sampler graph per (B, T'); going
+    back to an earlier shape must reproduce its earlier result bit for bit (same seed), whatever ran in between."""
+    m = _score_model(sd_np, "bf16")
+    w = tnoise.synth_noisy_speech(2, 20000, seed=11)
+    a = {"perturbed": torch.from_numpy(w[:, :9600]).cuda()}                 # T' = 64
+    b = {"perturbed": torch.from_numpy(w[:1, :20000]).cuda()}               # B = 1, T' = 128
+    first = m.sample(dict(a), N=2, corrector_steps=1, snr=0.5, seed=5)["enhanced"].clone()
+    other = m.sample(dict(b), N=2, corrector_steps=1, snr=0.5, seed=5)["enhanced"]
+    assert other.shape == (1, 20000) and torch.isfinite(other).all()
+    again = m.sample(dict(a), N=2, corrector_steps=1, snr=0.5, seed=5)["enhanced"]
+    assert torch.equal(first, again)
+    other2 = m.sample(dict(b), N=2, corrector_steps=1, snr=0.5, seed=5)["enhanced"]
+    assert torch.equal(other, other2)
