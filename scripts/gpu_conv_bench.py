@@ -24,6 +24,9 @@ CASES = {
     "L1 conv0 cat384->128":     (256, 320, 256, 128, 128, 0, 0, 1, 1, 1, 0),
     "L1 conv1 128->128 +sc384": (256, 320, 128, 0, 128, 256, 128, 1, 1, 0, 0),
     "L1 conv0 128->128 noact":  (256, 320, 128, 0, 128, 0, 0, 0, 0, 1, 0),
+    "L1 conv0 128->128":        (256, 320, 128, 0, 128, 0, 0, 1, 1, 1, 0),
+    "L1 conv1 128->128 +res":   (256, 320, 128, 0, 128, 0, 0, 1, 1, 0, 1),
+    "L1 conv0 256->256":        (256, 320, 256, 0, 256, 0, 0, 1, 1, 1, 0),
     "L2 conv0 256->256":        (128, 160, 256, 0, 256, 0, 0, 1, 1, 1, 0),
     "L2 conv1 256->256 +res":   (128, 160, 256, 0, 256, 0, 0, 1, 1, 0, 1),
     "L2 conv0 cat512->256":     (128, 160, 256, 256, 256, 0, 0, 1, 1, 1, 0),

@@ -806,3 +806,31 @@ def test_c_host_enhances_a_wav_file_like_the_python_path(tmp_path, sd_np):
     assert d.max() <= 164 and d.mean() < 2.0, (int(d.max()), float(d.mean()))
     bad = subprocess.run([exe, str(tmp_path / "missing.usehip"), str(tmp_path / "in.wav"), str(tmp_path / "o.wav")], capture_output=True, text=True)
     assert bad.returncode != 0 and "failed" in bad.stderr
+
+
+@pytest.mark.parametrize("dtype,tol", [(0, 2e-5), (1, 1.6e-2), (2, 2e-3)])
+def test_conv_sk_matches_the_generic_kernel(dtype, tol):
+    """conv_sk_kernel (split-K schedule of the small maps) against conv_kernel on the same seeded operands through the
+    single-convolution harness (use_conv_bench): plain / concatenated input, fused 1x1 shortcut, residual, no GroupNorm, odd map sizes
+    and the 96-channel shapes of the nf = 96 networks, both tile widths (B = 16 selects the 64-channel one).  Tolerance = one
+    rounding of the stored type relative to the largest output (different summation order); GroupNorm totals to 1e-3."""
+    import ctypes as C
+    from universal_speech_enhancement_amd import _lib
+    from universal_speech_enhancement_amd._lib import UseConvCase
+    # (B, H, W, C0, C1, Cout, XC0, XC1, act, gn, temb, res)
+    cases = [(4, 8, 10, 256, 0, 256, 0, 0, 1, 1, 1, 0), (4, 8, 10, 256, 256, 256, 0, 0, 1, 1, 1, 0), (4, 16, 20, 256, 0, 256, 256, 256, 1, 1, 0, 0),
+             (2, 16, 20, 256, 0, 256, 0, 0, 1, 1, 0, 1), (4, 8, 10, 256, 0, 256, 0, 0, 0, 0, 1, 0), (3, 7, 9, 96, 0, 96, 96, 96, 1, 1, 0, 0),
+             (2, 5, 33, 96, 64, 64, 0, 0, 1, 1, 1, 0), (16, 16, 20, 256, 0, 256, 0, 0, 1, 1, 1, 1)]
+    for (B, H, W, C0, C1, Cout, XC0, XC1, act, gn, temb, res) in cases:
+        got = {}
+        for variant in (1, 7):
+            c = UseConvCase(B, H, W, C0, C1, Cout, XC0, XC1, act, gn, temb, res, 1, dtype, variant, 1)
+            out = np.empty((B, H, W, Cout), np.float32); st = np.empty((B, Cout, 2), np.float32)
+            ms, fl = C.c_double(), C.c_double()
+            rc = _lib.lib().use_conv_bench(C.byref(c), out.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), C.byref(ms), C.byref(fl))
+            assert rc == 0, (variant, _lib.lib().use_last_error())
+            got[variant] = (out, st)
+        ref, sk = got[1], got[7]
+        assert np.isfinite(sk[0]).all()
+        assert np.abs(sk[0] - ref[0]).max() <= tol * np.abs(ref[0]).max(), (H, W, C0, C1, Cout, XC0)
+        assert np.abs(sk[1] - ref[1]).max() <= 1e-3 * np.abs(ref[1]).max()
