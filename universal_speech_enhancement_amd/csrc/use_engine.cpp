@@ -799,6 +799,7 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
     if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
+    if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
     if (!strcmp(name, "conv_sk_max_px")) { conv_sk_set_max_px((long)value); return USE_OK; }             // 0: conv_sk off
 #ifdef USE_HIP_EXPERIMENTS
     if (!strcmp(name, "conv_v5_min_blocks")) { conv_v5_set_min_blocks((long)value); return USE_OK; }

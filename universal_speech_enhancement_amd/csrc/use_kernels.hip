@@ -427,6 +427,142 @@ __global__ __launch_bounds__(256) void pyr_conv_kernel(ConvArgs p) {
         }
     }
 }
+// pyr_conv_pipe_kernel: the same layer, software-pipelined.  PMC of pyr_conv_kernel at 512x640: waves parked 47 % of their cycles,
+// VALU active 18 %, MFMA 12 % -- a workgroup loads its halo, waits, transforms, synchronises, multiplies, stores, and the two
+// workgroups a CU holds do not cover each other's waits.  Here a workgroup walks `tiles_per_wg` consecutive tiles of one item and
+// issues the halo loads of tile t+1 (registers) BEFORE it transforms and multiplies tile t; the weights of all taps (<= 2 blocks of
+// 128 input channels) and the GroupNorm affine of its channels are fetched once per workgroup.  Same arithmetic, same order.
+constexpr int PYRP_SMEM = PYR_HALO + 2 * PYR_WB + BM * 4 * 4;
+template <typename T16>
+__global__ __launch_bounds__(256) void pyr_conv_pipe_kernel(ConvArgs p, int tiles_per_wg) {
+    typedef Mfma<T16> MF;
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    char* const s_halo = psm;
+    char* const s_w = psm + PYR_HALO;                         // [nblk <= 2][9 taps x 4 rows][PYR_ROWB]
+    float* const s_out = reinterpret_cast<float*>(psm + PYR_HALO + 2 * PYR_WB);   // [128 pixels][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    const int tiles_x = (p.W + TILE_W - 1) / TILE_W, ntiles = tiles_x * ((p.H + TILE_H - 1) / TILE_H);
+    const int Cin = p.C0, nblk = Cin / PYR_CB;                // 1 or 2
+    const T16* src = (const T16*)p.src0;
+    const int part = tid % PYR_PP;
+    const int m = lane & 31;
+    const int a_base = (wave * 2 + (m >> 4)) * PYR_HPITCH + (m & 15) * PYR_ROWB + (lane >> 5) * 16;
+    const int b_base = (lane & 3) * PYR_ROWB + (lane >> 5) * 16;
+    constexpr int NP = ((TILE_H + 2) * (TILE_W + 2) * PYR_PP + 255) / 256;
+    // weights of every block, once
+    for (int i = tid; i < nblk * 9 * 4 * PYR_PP; i += 256) {
+        const int blk = i / (9 * 4 * PYR_PP), r0 = i - blk * (9 * 4 * PYR_PP);
+        const int pc = r0 % PYR_PP, row = r0 / PYR_PP;         // row = tap * 4 + co
+        const int tap = row >> 2, co = row & 3;
+        *reinterpret_cast<uint4*>(s_w + blk * PYR_WB + row * PYR_ROWB + pc * 16) =
+            *reinterpret_cast<const uint4*>((const T16*)p.w + ((size_t)co * 9 + tap) * Cin + blk * PYR_CB + pc * 8);
+    }
+    // GroupNorm affine of this thread's 8 channels of each block, once
+    float ca[2][8], cb[2][8];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            ca[blk][k] = 1.f; cb[blk][k] = 0.f;
+            if (blk < nblk) {
+                const int c = blk * PYR_CB + part * 8 + k;
+                if (p.gn_st0) {
+                    const float2 v = gn_coef_of(p.gn_st0, p.C0, p.gn_st1, p.C1, p.gn_gamma, p.gn_beta, p.gn_groups, p.gn_inv_n, p.gn_eps, b, c);
+                    ca[blk][k] = v.x; cb[blk][k] = v.y;
+                } else if (p.coef) {
+                    ca[blk][k] = p.coef[((size_t)b * Cin + c) * 2]; cb[blk][k] = p.coef[((size_t)b * Cin + c) * 2 + 1];
+                }
+            }
+        }
+    const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
+    const int nunits = (t_end - t_begin) * nblk;
+    uint4 rawN[NP]; int dstN[NP];
+    auto prefetch = [&](int u) {                             // unit u = (tile, block): issue its halo loads
+        const int tile = t_begin + u / nblk, c0 = (u % nblk) * PYR_CB;
+        const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int idx = j * 256 + tid, pix = idx / PYR_PP;
+            const int hy = pix / (TILE_W + 2), hx = pix - hy * (TILE_W + 2);
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const bool have = pix < (TILE_H + 2) * (TILE_W + 2);
+            const bool inb = have && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            dstN[j] = have ? (inb ? 1 : 2) * 0x100000 + hy * PYR_HPITCH + hx * PYR_ROWB + part * 16 : 0;
+            rawN[j] = inb ? *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.H + gy) * p.W + gx) * Cin + c0 + part * 8)
+                          : make_uint4(0, 0, 0, 0);
+        }
+    };
+    if (nunits > 0) prefetch(0);
+    f32x16 acc;
+    for (int u = 0; u < nunits; ++u) {
+        const int blk = u % nblk;
+        if (blk == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+        uint4 rawC[NP]; int dstC[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { rawC[j] = rawN[j]; dstC[j] = dstN[j]; }
+        if (u + 1 < nunits) prefetch(u + 1);                  // in flight behind this unit's transform + MFMAs
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            if (!dstC[j]) continue;
+            uint4 o = make_uint4(0, 0, 0, 0);                // outside the image: the conv's zero padding
+            if (dstC[j] < 0x200000) {
+                float v[8];
+                Vec16<T16>::load(reinterpret_cast<const T16*>(&rawC[j]), v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k] = fmaf(v[k], blk ? ca[1][k] : ca[0][k], blk ? cb[1][k] : cb[0][k]);
+                    if (p.act) v[k] = silu_f<false>(v[k]);
+                }
+                o = Vec16<T16>::pack(v);
+            }
+            *reinterpret_cast<uint4*>(s_halo + (dstC[j] & 0xfffff)) = o;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const char* ha = s_halo + a_base + (tap / 3) * PYR_HPITCH + (tap % 3) * PYR_ROWB;
+            const char* wb = s_w + blk * PYR_WB + b_base + tap * 4 * PYR_ROWB;
+#pragma unroll
+            for (int kk = 0; kk < PYR_CB / 16; ++kk) acc = MF::mma(MF::ld(ha + kk * 32), MF::ld(wb + kk * 32), acc);
+        }
+        if (blk == nblk - 1) {                                // tile complete: [128 px][4] through LDS, one pixel per thread
+            const int tile = t_begin + u / nblk;
+            const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
+            if ((lane & 31) < 4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    s_out[(wave * 32 + row) * 4 + (lane & 31)] = acc[r];
+                }
+            }
+            __syncthreads();                                  // also: every wave is done with the halo
+            if (tid < TILE_H * TILE_W) {
+                const int gy = ty0 + (tid >> 4), gx = tx0 + (tid & 15);
+                if (gy < p.H && gx < p.W) {
+                    const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
+                    float4 v = *reinterpret_cast<const float4*>(s_out + tid * 4);
+                    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (c < p.Cout && p.bias) o[c] += p.bias[c];
+                    if (p.res) {
+                        const float* rp = (const float*)p.res + pix * p.Cout;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (c < p.Cout) o[c] += rp[c];
+                    }
+                    float* op = (float*)p.out + pix * p.Cout;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (c < p.Cout) op[c] = o[c] * p.out_scale;
+                }
+            }
+        } else {
+            __syncthreads();                                  // every wave is done with the halo of this block
+        }
+    }
+}
 static bool pyr_conv_eligible(const ConvArgs& a) {
     return a.in_dtype != DT_F32 && a.out_dtype == DT_F32 && a.ntaps == 9 && a.Cout <= 4 && a.C1 == 0 && a.C0 % PYR_CB == 0 &&
            !a.temb && !a.pyr && !a.stats && a.XC0 + a.XC1 == 0;
@@ -718,6 +854,8 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     launch_conv_generic(a, s);
 }
 
+static int g_pyr_pipe = 128;      // workgroups per item of pyr_conv_pipe_kernel (0: the one-tile-per-workgroup form)
+void pyr_conv_set_pipe(int n) { g_pyr_pipe = n; }
 void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
     if (pyr_conv_eligible(a)) {
         static bool attr_set = false;
@@ -726,8 +864,22 @@ void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, PYR_SMEM);
             attr_set = true;
         }
-        if (a.in_dtype == DT_BF16) hipLaunchKernelGGL(pyr_conv_kernel<__bf16>, dim3(tiles_per_image(a.H, a.W), 1, a.B), dim3(256), PYR_SMEM, s, a);
-        else                       hipLaunchKernelGGL(pyr_conv_kernel<_Float16>, dim3(tiles_per_image(a.H, a.W), 1, a.B), dim3(256), PYR_SMEM, s, a);
+        const int ntiles = tiles_per_image(a.H, a.W);
+        if (a.C0 <= 2 * PYR_CB && g_pyr_pipe) {              // pipelined form: <= 2 workgroups per CU worth of workgroups per item, several tiles each
+            static bool attr2 = false;
+            if (!attr2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_pipe_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, PYRP_SMEM);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_pipe_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, PYRP_SMEM);
+                attr2 = true;
+            }
+            const int tpw = (ntiles + g_pyr_pipe - 1) / g_pyr_pipe;
+            const dim3 grid((ntiles + tpw - 1) / tpw, 1, a.B);
+            if (a.in_dtype == DT_BF16) hipLaunchKernelGGL(pyr_conv_pipe_kernel<__bf16>, grid, dim3(256), PYRP_SMEM, s, a, tpw);
+            else                       hipLaunchKernelGGL(pyr_conv_pipe_kernel<_Float16>, grid, dim3(256), PYRP_SMEM, s, a, tpw);
+            return;
+        }
+        if (a.in_dtype == DT_BF16) hipLaunchKernelGGL(pyr_conv_kernel<__bf16>, dim3(ntiles, 1, a.B), dim3(256), PYR_SMEM, s, a);
+        else                       hipLaunchKernelGGL(pyr_conv_kernel<_Float16>, dim3(ntiles, 1, a.B), dim3(256), PYR_SMEM, s, a);
         return;
     }
     if (conv_in_eligible(a)) {
