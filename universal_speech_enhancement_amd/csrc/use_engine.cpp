@@ -799,6 +799,7 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
     if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
+    if (!strcmp(name, "conv_v7_min_units")) { conv_v7_set_min_units((long)value); return USE_OK; }   // 0: conv_v7 off
     if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
     if (!strcmp(name, "conv_sk_max_px")) { conv_sk_set_max_px((long)value); return USE_OK; }             // 0: conv_sk off
 #ifdef USE_HIP_EXPERIMENTS
@@ -1448,6 +1449,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             case 7: if (!conv_sk_eligible(a)) return -1; launch_conv_sk(a, 0); return 0;
             case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
             case 4: if (!a.wb || (XC && !a.w2b)) return -1; launch_conv_v4(a, 0); return 0;
+            case 8: if (!conv_v7_supports(a)) return -1; launch_conv_v7(a, 0); return 0;
 #ifdef USE_HIP_EXPERIMENTS
             case 5: if (!a.wb || (XC && !a.w2b) || dt == DT_F32) return -1; launch_conv_v5(a, 0); return 0;
             case 6: if (!conv_v6_eligible(a)) return -1; launch_conv_v6(a, 0); return 0;
@@ -1467,8 +1469,13 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
     if (trace) {
         unsigned long long hb[512];
         (void)hipMemcpy(hb, trace, sizeof hb, hipMemcpyDeviceToHost);
-        unsigned long long prev = hb[1];
-        for (int i = 0; i < 250 && hb[2 * i]; ++i) { fprintf(stderr, "[trace] id %3llu  +%6llu\n", hb[2 * i], hb[2 * i + 1] - prev); prev = hb[2 * i + 1]; }
+        for (int g = 0; g < 2; ++g) {                           // wave 0 / wave 4 (conv_v4 / conv_v7 stamp both wave groups)
+            unsigned long long prev = hb[g * 256 + 1];
+            for (int i = 0; i < 125 && hb[g * 256 + 2 * i]; ++i) {
+                fprintf(stderr, "[trace G%d] id %3llu  +%6llu  @%8llu\n", g, hb[g * 256 + 2 * i], hb[g * 256 + 2 * i + 1] - prev, hb[g * 256 + 2 * i + 1] - hb[1]);
+                prev = hb[g * 256 + 2 * i + 1];
+            }
+        }
         a.trace = nullptr;
     }
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);

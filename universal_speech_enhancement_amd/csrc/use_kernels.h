@@ -87,6 +87,12 @@ void pyr_conv_set_pipe(int n);                           // pyramid-head convolu
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 128 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);
+// persistent form of conv_v4 (use_conv_v7.hip): one workgroup per CU walks a range of tiles of one item with the next tile's first
+// halo chunk staged behind the current tile's last MFMAs; LDS-free epilogue (swapped MFMA operands); 16-bit storage, no fused shortcut / Combine
+bool conv_v7_supports(const ConvArgs& a);                 // the shapes / fusions the kernel implements
+bool conv_v7_eligible(const ConvArgs& a);                 // ... and large enough to be dispatched to it
+void conv_v7_set_min_units(long n);                      // smallest per-image unit count (tiles x channel blocks) it is used for; 0: off
+void launch_conv_v7(const ConvArgs& a, hipStream_t s);
 // GroupNorm finalisation for the consumers that take a coefficient array (FIR resampling kernels): per-(b, group) mean / rstd
 // from the per-channel totals of up to two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b): y = a*x + b.
 void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta,
