@@ -27,3 +27,7 @@ show("1 tile res  ", (16, 32, 128, 0, 128, 0, 0, 1, 1, 1, 1))
 show("2x2 tiles   ", (32, 64, 128, 0, 128, 0, 0, 1, 1, 1, 1))
 show("2x2 nb2     ", (32, 64, 128, 0, 256, 0, 0, 1, 1, 1, 1))
 show("4x4 cat B3  ", (64, 128, 128, 64, 128, 0, 0, 1, 1, 1, 1), B=3)
+show("1 tile sc128", (16, 32, 128, 0, 128, 128, 0, 1, 1, 1, 0))
+show("2x2 sc cat  ", (32, 64, 128, 0, 128, 128, 128, 1, 1, 0, 0))
+show("4x4 sc384 B3", (64, 128, 128, 0, 128, 256, 128, 1, 1, 0, 0), B=3)
+show("2x2 nb2 sc  ", (32, 64, 128, 128, 256, 256, 0, 1, 1, 1, 0), B=2)

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <algorithm>
 
 namespace use {
 
@@ -38,7 +39,9 @@ constexpr int V7_OFF_W = 2 * V7_HALO;                      // 97,920
 constexpr int V7_OFF_COEF = V7_OFF_W + 2 * V7_WSLAB;       // 114,304: GroupNorm affine of the item's input channels (<= 512 x float2)
 constexpr int V7_OFF_BIAS = V7_OFF_COEF + 4096;            // 118,400: bias + time embedding of the unit's 128 channels
 constexpr int V7_OFF_TOT = V7_OFF_BIAS + 512;              // 118,912: [Cout <= 256][2] int64 GroupNorm totals of this workgroup
-constexpr int V7_SMEM = V7_OFF_TOT + 4096;                 // 123,008
+constexpr int V7_OFF_S = V7_OFF_TOT + 4096;                // 123,008: shortcut operand, even chunks: 512 centre pixels x 64 B, piece-swizzled
+constexpr int V7_SBYTES = V7_TH * V7_TW * V7_CK * 2;       // 32,768   (odd chunks go to the halo buffer the last 3x3 chunk has left)
+constexpr int V7_SMEM = V7_OFF_S + V7_SBYTES;              // 155,776
 
 struct V7Plan {
     int wpi;          // workgroups per batch item
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(512) void conv_v7_kernel(ConvArgs p, V7Plan q) {
     unsigned long long* const tot_lds = reinterpret_cast<unsigned long long*>(smem + V7_OFF_TOT);
 
     // GroupNorm affine of the chunk being staged: (a, b) pairs of this thread's 8 channels exactly as the table holds them - four
-    // 16-byte registers that double as parking space for residual pieces at the end of a unit (see res_load_a)
+    // 16-byte registers that double as staging registers of the shortcut segment (which has no transform)
     uint4 cq[4];
     auto load_coef = [&](int chunk) {
         int part_o = part;                                   // opaque: the table base is recomputed (1 VALU) instead of living in - or
@@ -214,7 +217,8 @@ __global__ __launch_bounds__(512) void conv_v7_kernel(ConvArgs p, V7Plan q) {
     frag af[KSTEPS][TM], bf[KSTEPS][TN];                      // af: pixel fragments (MFMA B operand), bf: weight fragments (A operand)
     uint4 hLa = wa, hLb = wa, hT = wa, t0 = wa;              // pieces in flight (even / odd), piece being transformed, transformed piece
     unsigned mT = 0;                                         // mask of the piece being transformed
-    int gpar = 0;                                            // halo buffer the current chunk reads (flips per chunk)
+    int gpar = 0;                                            // halo buffer the current chunk reads (flips per 3x3 chunk)
+    int wpar = 0;                                            // weight buffer the current iteration reads is wpar ^ (T & 1) (flips per iteration)
     bool nx_valid = true;                                    // a next chunk exists (this unit's next chunk, or chunk 0 of the next unit)
     int c_next = 0, n0_w2 = n0;                              // next chunk index; channel block of the iterations that wrap past this chunk
     int c = 0;
@@ -223,8 +227,7 @@ __global__ __launch_bounds__(512) void conv_v7_kernel(ConvArgs p, V7Plan q) {
 
     const size_t img_elems = img_px * p.Cout;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((TIN*)p.out + (size_t)b * img_elems, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIN*>((const TIN*)p.res) + (size_t)b * img_elems, 0, 0x7fffffff, 0x00020000);
-    const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
+    const bool has_stats = p.stats != nullptr;
 
     // one-hot fragments: element e of lane (x = lane & 31, h = lane >> 5) is 1 where x == 16 gp + 8 h + e.  Rebuilt where they are
     // used (a dozen VALU instructions) instead of living in 16 registers across the main loop.
@@ -240,25 +243,34 @@ __global__ __launch_bounds__(512) void conv_v7_kernel(ConvArgs p, V7Plan q) {
             voff[i] = (unsigned)(((gy * p.W + t_x0 + (lane_o & 31)) * p.Cout + n0w) * 2 + (lane_o >> 5) * 16);
         }
     };
-    // residual of the current unit: 16 bytes = 8 consecutive channels of this lane's pixel = the B fragment of acc += OneHot x residual
-    // (exact: one product with 1.0 per element; last term of the sum as in conv_v4).  vmcnt retires in order, so a load issued behind
-    // the epilogue's stores would wait for them: channel blocks 0-1 are fetched in LDS(7) of the unit's last chunk, blocks 2-3 at the
-    // very start of the epilogue, all before the first store.  The 16 pieces are parked in variables that are dead at those points -
-    // the staging registers (hLa, hLb, hT, t0, cq) and the weight fragments bf - by name: a fresh array costs hipcc's register
-    // allocator 48 spilled registers here.
-    auto res_piece = [&](const unsigned (&voff)[TM], int j, int i, int gp) -> uint4 {
-        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff[i] + (unsigned)(j * 64 + gp * 32), 0, 0));
+    // ---- shortcut segment (the res-block's 1x1 Conv_2 on the raw block input - or the residual, as an identity matrix): XC / 32 extra
+    // chunks of ONE tap each after the 3x3 chunks.  Its operand is the tile's 512 raw centre pixels, 4 pieces per thread per chunk,
+    // staged through the registers the halo pipeline leaves idle (no transform here): chunk s is loaded in iteration s-2, written to
+    // LDS in iteration s-1 (even chunks: the region S0; odd chunks: the halo buffer the last 3x3 chunk has left), read in iteration s.
+    const int nsc = (p.XC0 + p.XC1) / V7_CK;
+    const TIN* const x0_b = nsc ? (const TIN*)p.x0 + (size_t)b * img_px * p.XC0 : nullptr;
+    const TIN* const x1_b = (nsc && p.x1) ? (const TIN*)p.x1 + (size_t)b * img_px * p.XC1 : nullptr;
+    auto sc_ld = [&](int chunk2, int qq) -> uint4 {
+        int pix0_o = pix0;
+        asm volatile("" : "+v"(pix0_o));
+        const int c_glob = chunk2 * V7_CK;
+        const TIN* src; int Cs, c_loc;
+        if (c_glob < p.XC0) { src = x0_b; Cs = p.XC0; c_loc = c_glob; }
+        else                { src = x1_b; Cs = p.XC1; c_loc = c_glob - p.XC0; }
+        const int pixoff = (ty0 + qq * 4 + (pix0_o >> 5)) * p.W + tx0 + (pix0_o & 31);
+        return buf_ld(src, (unsigned)pixoff * (unsigned)(Cs * 2) + (unsigned)(part * 16), (unsigned)(c_loc * 2));
     };
-    auto res_load_a = [&]() {                                // channel blocks 0, 1: piece (j, i, gp) -> slot (j * 2 + i) * 2 + gp
-        int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));
-        unsigned voff[TM];
-        out_offsets(lane_o, ty0, tx0, n0, voff);
-        hLa = res_piece(voff, 0, 0, 0); hLb = res_piece(voff, 0, 0, 1); hT = res_piece(voff, 0, 1, 0); t0 = res_piece(voff, 0, 1, 1);
-        cq[0] = res_piece(voff, 1, 0, 0); cq[1] = res_piece(voff, 1, 0, 1); cq[2] = res_piece(voff, 1, 1, 0); cq[3] = res_piece(voff, 1, 1, 1);
+    auto sc_st = [&](int sbase, const uint4& r0, const uint4& r1, const uint4& r2, const uint4& r3) {
+        int pix0_o = pix0;
+        asm volatile("" : "+v"(pix0_o));
+        char* d = smem + sbase + pix0_o * 64 + ((part ^ ((pix0_o >> 2) & 3)) * 16);       // 64-byte pixel rows, piece-swizzled like the weights
+        *reinterpret_cast<uint4*>(d) = r0; *reinterpret_cast<uint4*>(d + 8192) = r1;
+        *reinterpret_cast<uint4*>(d + 16384) = r2; *reinterpret_cast<uint4*>(d + 24576) = r3;
     };
-
-    bool res_now = false;                                    // this chunk is the unit's last and the unit has a residual
+    auto w2_ld = [&](int chunk2) -> uint4 {
+        return buf_ld(p.w2b, wvoff, (unsigned)chunk2 * slab_b + (unsigned)(n0 * V7_CK) * 2u);
+    };
+    bool sc_now = false;                                     // this is the unit's last 3x3 chunk and a shortcut segment follows
     // Piece k (0..4) of the next chunk: global load issued in LDS(k) -> parked in plain registers in LDS(k+2) (two pieces in flight:
     // at a unit switch the whole chip asks for new pixels at once and one iteration does not cover that latency) -> GroupNorm+SiLU on
     // the VALU behind the MFMAs of MFMA(k+2) -> written to the other halo buffer in LDS(k+3).
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(512) void conv_v7_kernel(ConvArgs p, V7Plan q) {
         constexpr int T = decltype(Tc)::value;
         {
             const char* ha_ = smem + gpar * HALO + (T / 3) * HPITCH + (T % 3) * ROWB + a_base;
-            const int wbuf_ = (gpar ^ (T & 1)) * V7_WSLAB;
+            const int wbuf_ = (wpar ^ (T & 1)) * V7_WSLAB;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
 #pragma unroll
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(512) void conv_v7_kernel(ConvArgs p, V7Plan q) {
             constexpr int k_ = T - 3;
             if (nx_valid && (k_ < 4 || tid < 400)) *reinterpret_cast<uint4*>(smem + (gpar ^ 1) * HALO + pdst0 + k_ * 10240) = t0;
         }
-        if (T < 8 || nx_valid) w_st((gpar ^ (T & 1)) ^ 1, wa);
+        if (T < 8 || nx_valid || sc_now) w_st((wpar ^ (T & 1)) ^ 1, wa);
         if constexpr (T >= 2 && T < 7) {
             // the piece loaded two iterations ago has landed: park it in plain registers so that the MFMA-phase transform carries no
             // vmcnt wait on the fresh loads
@@ -293,13 +305,60 @@ __global__ __launch_bounds__(512) void conv_v7_kernel(ConvArgs p, V7Plan q) {
                 if constexpr (T & 1) hLb = src_ld(c_next, ppix[T]); else hLa = src_ld(c_next, ppix[T]);
             }
         }
-        if constexpr (T == 8) {
-            // (here, not earlier: with loads pending on one path only, hipcc's counter merge turns the next weight wait into vmcnt(0))
-            if (res_now) res_load_a();
+        if constexpr (T == 7) {
+            if (sc_now) { hLa = sc_ld(0, 0); hLb = sc_ld(0, 1); hT = sc_ld(0, 2); t0 = sc_ld(0, 3); }
         }
-        // weights of iteration T+2 (wraps into the next chunk / the next unit's chunk 0)
+        if constexpr (T == 8) {
+            if (sc_now) {
+                sc_st(V7_OFF_S, hLa, hLb, hT, t0);
+                cq[0] = sc_ld(1, 0); cq[1] = sc_ld(1, 1); cq[2] = sc_ld(1, 2); cq[3] = sc_ld(1, 3);
+            }
+        }
+        // weights of iteration T+2 (wraps into the next chunk / the shortcut segment / the next unit's chunk 0)
         if constexpr (T + 2 <= 8) wa = w_ld(T + 2, c, n0);
+        else if (sc_now) wa = w2_ld(T + 2 - 9);
         else if (nx_valid) wa = w_ld(T + 2 - 9, c_next, n0_w2);
+    };
+    // one shortcut chunk (parity P of its index is a compile-time constant: it selects the register set and the LDS region)
+    auto sc_lds_phase = [&](auto Pc, int sidx, bool more_) {
+        constexpr int P = decltype(Pc)::value;
+        const int s1base = (gpar ^ 1) * HALO;                // (gpar already points at the next unit's first chunk)
+        {
+            // w_base carries the lane's swizzled offset (+ V7_OFF_W); opaque copies: the sums are rebuilt here (2 VALU) instead of being
+            // hoisted out of the unit loop and spilled around the 3x3 chunks
+            int wb0 = w_base0, wb1 = w_base1;
+            asm volatile("" : "+v"(wb0), "+v"(wb1));
+            const int sb_ = (P ? s1base : V7_OFF_S) + wave_u * 4096 - V7_OFF_W;
+            const int sa0 = sb_ + wb0, sa1 = sb_ + wb1;
+            const int wbuf_ = wpar * V7_WSLAB;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[kk][i] = MF::ld(smem + (kk ? sa1 : sa0) + i * 2048);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[kk][j] = MF::ld(smem + wbuf_ + (kk ? w_base1 : w_base0) + j * 2048);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (sidx + 1 < nsc) {                                // chunk s+1 (loaded one iteration ago) -> the other region
+            if constexpr (P) sc_st(V7_OFF_S, hLa, hLb, hT, t0); else sc_st(s1base, cq[0], cq[1], cq[2], cq[3]);
+        }
+        if (sidx + 1 < nsc || more_) w_st(wpar ^ 1, wa);
+        if (sidx + 2 < nsc) {                                // chunk s+2 -> this chunk's register set
+            if constexpr (P) { cq[0] = sc_ld(sidx + 2, 0); cq[1] = sc_ld(sidx + 2, 1); cq[2] = sc_ld(sidx + 2, 2); cq[3] = sc_ld(sidx + 2, 3); }
+            else { hLa = sc_ld(sidx + 2, 0); hLb = sc_ld(sidx + 2, 1); hT = sc_ld(sidx + 2, 2); t0 = sc_ld(sidx + 2, 3); }
+            wa = w2_ld(sidx + 2);
+        } else if (more_) {
+            wa = w_ld(sidx + 2 - nsc, 0, n0n);               // the next unit's taps 0 / 1
+        }
+    };
+    auto sc_mfma_phase = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(bf[kk][j], af[kk][i], acc[i][j]);
     };
     auto mfma_phase = [&](auto Tc) {
         constexpr int T = decltype(Tc)::value;
@@ -352,30 +411,8 @@ __global__ __launch_bounds__(512) void conv_v7_kernel(ConvArgs p, V7Plan q) {
         unsigned voff[TM];
         out_offsets(lane_o, ty0, tx0, n0, voff);
         const float scale = p.out_scale;
-        auto radd = [&](int i, int j, int gp, const uint4& piece) {
-            acc[i][j] = MF::mma(__builtin_bit_cast(frag, selu[gp]), __builtin_bit_cast(frag, piece), acc[i][j]);
-        };
-        if (has_res) {
-            // blocks 2, 3 into the dead weight fragments: bf[gp][(j - 2) * 2 + i]
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) bf[gp][jj * 2 + i] = __builtin_bit_cast(frag, res_piece(voff, 2 + jj, i, gp));
-            radd(0, 0, 0, hLa); radd(0, 0, 1, hLb); radd(1, 0, 0, hT); radd(1, 0, 1, t0);
-            radd(0, 1, 0, cq[0]); radd(0, 1, 1, cq[1]); radd(1, 1, 0, cq[2]); radd(1, 1, 1, cq[3]);
-        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            if (has_res && j == 2) {
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int gp = 0; gp < 2; ++gp) radd(i, 2 + jj, gp, __builtin_bit_cast(uint4, bf[gp][jj * 2 + i]));
-            }
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
                 // GroupNorm partial sums of 16 channels on the matrix pipe: (lane = pixel, 8 channels) x OneHot -> accumulator with
@@ -453,7 +490,7 @@ __global__ __launch_bounds__(512) void conv_v7_kernel(ConvArgs p, V7Plan q) {
             trace_fine = ((p.dbg >> 20) & 1) && trace_n > 20 && trace_n < 100 && (c == 0 || last);
 #endif
             nx_valid = !last || more;
-            res_now = last && has_res;
+            sc_now = last && nsc > 0;
             c_next = last ? 0 : c + 1;
             n0_w2 = last ? n0n : n0;
             lds_phase(std::integral_constant<int, 0>{}); V7_BAR(); mfma_phase(std::integral_constant<int, 0>{}); V7_BAR();
@@ -467,9 +504,14 @@ __global__ __launch_bounds__(512) void conv_v7_kernel(ConvArgs p, V7Plan q) {
             if (last && more && q.nb > 1 && tid < V7_BN) fill_bias(n0n);      // read after the epilogue, many barriers from here
             V7_BAR(); mfma_phase(std::integral_constant<int, 7>{}); V7_BAR();
             lds_phase(std::integral_constant<int, 8>{}); V7_BAR(); mfma_phase(std::integral_constant<int, 8>{});
-            gpar ^= 1;
+            gpar ^= 1; wpar ^= 1;
             V7_STAMP(20 + c)
-            if (!last) V7_BAR();
+            if (!last || nsc > 0) V7_BAR();
+        }
+        for (int sidx = 0; sidx < nsc; sidx += 2) {          // shortcut chunks, two per trip (static register sets)
+            sc_lds_phase(std::integral_constant<int, 0>{}, sidx, more); V7_BAR(); sc_mfma_phase(); V7_BAR(); wpar ^= 1;
+            sc_lds_phase(std::integral_constant<int, 1>{}, sidx + 1, more); V7_BAR(); sc_mfma_phase(); wpar ^= 1;
+            if (sidx + 2 < nsc) V7_BAR();
         }
         if (wave_u < 4) V7_BAR();                            // G0's MFMA(8) barrier; G1 runs on into its epilogue
         if (!abl_noepi) epilogue();
@@ -507,27 +549,71 @@ static void v7_launch_t(const ConvArgs& a, const V7Plan& q, int grid, hipStream_
 }
 
 static long g_v7_min_units = 0;     // 0: off
+static long g_v7_max_units = 1L << 40;
 static int g_v7_cus = 0;
+static int g_v7_modes = 7;          // bit 0: plain convolutions, 1: with a residual, 2: with a fused 1x1 shortcut
 void conv_v7_set_min_units(long n) { g_v7_min_units = n; }
+void conv_v7_set_max_units(long n) { g_v7_max_units = n; }
+void conv_v7_set_modes(int m) { g_v7_modes = m; }
+static int g_v7_upw = 0;            // units per workgroup (0: as many as an even split over the CUs gives)
+void conv_v7_set_units_per_wg(int n) { g_v7_upw = n; }
+
+// The residual of a convolution is served as an identity shortcut: out = conv3x3(in) + I x res.  Identity slabs in the slab-major,
+// piece-swizzled weight layout ([chunk][cout_pad][32]; element (n, k = n) of chunk n / 32), one per (Cout, dtype), built on first use -
+// the engine asks for them at plan time (conv_v7_prepare), never inside a stream capture.
+struct V7Ident { int cout, dtype; void* dev; };
+static V7Ident g_v7_ident[8];
+static int g_v7_nident = 0;
+static const void* v7_identity(int cout, int dtype, bool create) {
+    for (int i = 0; i < g_v7_nident; ++i)
+        if (g_v7_ident[i].cout == cout && g_v7_ident[i].dtype == dtype) return g_v7_ident[i].dev;
+    if (!create || g_v7_nident == 8) return nullptr;
+    const int nch = cout / V7_CK;
+    const size_t elems = (size_t)nch * cout * V7_CK;
+    unsigned short* h = (unsigned short*)calloc(elems, 2);
+    if (!h) return nullptr;
+    const unsigned short one = dtype == DT_BF16 ? 0x3F80 : 0x3C00;
+    for (int n = 0; n < cout; ++n) {
+        const int ch = n / V7_CK, kk = n % V7_CK, q = kk / 8, e = kk % 8, pos = q ^ ((n >> 2) & 3);
+        h[((size_t)ch * cout + n) * V7_CK + pos * 8 + e] = one;
+    }
+    void* d = nullptr;
+    if (hipMalloc(&d, elems * 2) != hipSuccess) { free(h); return nullptr; }
+    (void)hipMemcpy(d, h, elems * 2, hipMemcpyHostToDevice);
+    free(h);
+    g_v7_ident[g_v7_nident++] = V7Ident{cout, dtype, d};
+    return d;
+}
+void conv_v7_prepare(int cout, int dtype) {
+    if (dtype != DT_F32 && cout % V7_BN == 0 && cout <= 256) (void)v7_identity(cout, dtype, true);
+}
 
 bool conv_v7_supports(const ConvArgs& a) {
-    const int Ctot = a.C0 + a.C1;
-    return a.wb != nullptr && a.ntaps == 9 && a.in_dtype != DT_F32 && a.in_dtype == a.out_dtype && a.XC0 + a.XC1 == 0 && a.pyr == nullptr &&
+    const int Ctot = a.C0 + a.C1, XC = a.XC0 + a.XC1;
+    const bool sc_ok = XC == 0 || (a.w2b != nullptr && a.res == nullptr && XC % (2 * V7_CK) == 0 && (a.XC1 == 0 || a.XC0 % V7_CK == 0));
+    return a.wb != nullptr && a.ntaps == 9 && a.in_dtype != DT_F32 && a.in_dtype == a.out_dtype && sc_ok && a.pyr == nullptr &&
            Ctot % V7_CK == 0 && Ctot >= 2 * V7_CK && Ctot <= 512 && (a.C1 == 0 || a.C0 % V7_CK == 0) && a.Cout % V7_BN == 0 && a.Cout <= 256 &&
-           a.cout_pad % V7_BN == 0 && a.H % V7_TH == 0 && a.W % V7_TW == 0;
+           a.cout_pad == a.Cout && a.H % V7_TH == 0 && a.W % V7_TW == 0;
 }
 bool conv_v7_eligible(const ConvArgs& a) {
     if (g_v7_min_units <= 0) return false;
     const long units = (long)conv_v4_tiles(a.H, a.W) * ((a.Cout + V7_BN - 1) / V7_BN);
-    return units >= g_v7_min_units && conv_v7_supports(a);
+    if (units < g_v7_min_units || units > g_v7_max_units || !conv_v7_supports(a)) return false;
+    const int mode = a.res ? 2 : (a.XC0 + a.XC1) ? 4 : 1;
+    if (!(g_v7_modes & mode)) return false;
+    return a.res == nullptr || v7_identity(a.Cout, a.in_dtype, false) != nullptr;     // (the identity slabs must exist already: no allocation here)
 }
 
-void launch_conv_v7(const ConvArgs& a, hipStream_t s) {
+void launch_conv_v7(const ConvArgs& a0, hipStream_t s) {
     if (!g_v7_cus) {
         int dev = 0, n = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         g_v7_cus = n > 0 ? n : 256;
+    }
+    ConvArgs a = a0;
+    if (a.res) {                                             // residual -> identity shortcut (exact: one product with 1.0 per element)
+        a.x0 = a.res; a.XC0 = a.Cout; a.x1 = nullptr; a.XC1 = 0; a.w2b = v7_identity(a.Cout, a.in_dtype, true); a.res = nullptr;
     }
     V7Plan q;
     q.nb = a.Cout / V7_BN;
@@ -535,6 +621,8 @@ void launch_conv_v7(const ConvArgs& a, hipStream_t s) {
     q.units = conv_v4_tiles(a.H, a.W) * q.nb;
     q.wpi = g_v7_cus / a.B;
     if (q.wpi < 1) q.wpi = 1;
+    // bounded walks: a workgroup that holds its CU for the whole launch keeps the other sub-batch's small kernels waiting
+    if (g_v7_upw > 0) q.wpi = std::max(q.wpi, (q.units + g_v7_upw - 1) / g_v7_upw);
     if (q.wpi > q.units) q.wpi = q.units;
     const int grid = q.wpi * a.B;
     if (a.in_dtype == DT_BF16) { a.act ? v7_launch_t<__bf16, true>(a, q, grid, s) : v7_launch_t<__bf16, false>(a, q, grid, s); }

@@ -461,6 +461,7 @@ struct Fwd {
         h->flops += fl;
         // large maps: separate finalize launch into a coefficient array (allocated in the dry run as well: the arena is sized by it)
         const float* coef_arr = (gn && (long)a.H * a.W > g_gn_inline) ? gn_coef(a, a2, *gn) : nullptr;
+        if (res) conv_v7_prepare(w.cout, a.dtype);            // identity slabs of the residual-as-shortcut form (built once, outside any capture)
         if (h->dry) return o;
         ConvArgs p{};
         p.src0 = a.p; p.C0 = a.C; p.src1 = a2 ? a2->p : nullptr; p.C1 = a2 ? a2->C : 0; p.in_dtype = a.dtype;
@@ -480,7 +481,7 @@ struct Fwd {
         p.pyr = pyr; p.w4 = cb ? W<float>(cb->w_off) : nullptr; p.b4 = cb ? W<float>(cb->b_off) : nullptr;
         p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
         p.B = B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
-        const bool main_variant = conv_v4_eligible(p);        // the dominant kernel (conv_v4_kernel, large maps)
+        const bool main_variant = conv_v4_eligible(p) || conv_v7_eligible(p);        // the dominant kernel (conv_v4_kernel / conv_v7_kernel, large maps)
         if (h->profile && (main_variant || (h->profile_all && conv_v2_eligible(p)))) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, s);
@@ -800,6 +801,9 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
     if (!strcmp(name, "conv_v7_min_units")) { conv_v7_set_min_units((long)value); return USE_OK; }   // 0: conv_v7 off
+    if (!strcmp(name, "conv_v7_units_per_wg")) { conv_v7_set_units_per_wg((int)value); return USE_OK; }
+    if (!strcmp(name, "conv_v7_max_units")) { conv_v7_set_max_units((long)value); return USE_OK; }
+    if (!strcmp(name, "conv_v7_modes")) { conv_v7_set_modes((int)value); return USE_OK; }           // bit 0: plain, 1: residual, 2: fused shortcut
     if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
     if (!strcmp(name, "conv_sk_max_px")) { conv_sk_set_max_px((long)value); return USE_OK; }             // 0: conv_sk off
 #ifdef USE_HIP_EXPERIMENTS
@@ -1449,7 +1453,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             case 7: if (!conv_sk_eligible(a)) return -1; launch_conv_sk(a, 0); return 0;
             case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
             case 4: if (!a.wb || (XC && !a.w2b)) return -1; launch_conv_v4(a, 0); return 0;
-            case 8: if (!conv_v7_supports(a)) return -1; launch_conv_v7(a, 0); return 0;
+            case 8: if (!conv_v7_supports(a)) return -1; conv_v7_prepare(a.Cout, a.in_dtype); launch_conv_v7(a, 0); return 0;
 #ifdef USE_HIP_EXPERIMENTS
             case 5: if (!a.wb || (XC && !a.w2b) || dt == DT_F32) return -1; launch_conv_v5(a, 0); return 0;
             case 6: if (!conv_v6_eligible(a)) return -1; launch_conv_v6(a, 0); return 0;

@@ -91,8 +91,12 @@ void launch_conv_v4(const ConvArgs& a, hipStream_t s);
 // halo chunk staged behind the current tile's last MFMAs; LDS-free epilogue (swapped MFMA operands); 16-bit storage, no fused shortcut / Combine
 bool conv_v7_supports(const ConvArgs& a);                 // the shapes / fusions the kernel implements
 bool conv_v7_eligible(const ConvArgs& a);                 // ... and large enough to be dispatched to it
+void conv_v7_set_modes(int m);                           // which convolutions go to it: bit 0 plain, 1 residual, 2 fused shortcut
+void conv_v7_set_units_per_wg(int n);                    // length of a workgroup's walk (0: even split over the CUs)
+void conv_v7_set_max_units(long n);
 void conv_v7_set_min_units(long n);                      // smallest per-image unit count (tiles x channel blocks) it is used for; 0: off
 void launch_conv_v7(const ConvArgs& a, hipStream_t s);
+void conv_v7_prepare(int cout, int dtype);               // builds the identity slabs a residual convolution needs (plan time, outside any capture)
 // GroupNorm finalisation for the consumers that take a coefficient array (FIR resampling kernels): per-(b, group) mean / rstd
 // from the per-channel totals of up to two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b): y = a*x + b.
 void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta,
