@@ -212,3 +212,13 @@ def test_packed_weight_file_is_written_on_the_host(tmp_path):
         e.save_weight_blob(str(tmp_path / "empty.usehip"))
     e.close()
 
+
+
+def test_train_step_refuses_frame_counts_it_would_have_to_pad():
+    """The reference's train_step feeds the UNPADDED num_frames-frame spectrogram to the network (model_wrapper.py:168-171), which only
+    closes for multiples of 64 frames; the stand-in must not silently zero-pad another count (extra frames in z and in the loss)."""
+    import torch
+    from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel
+    m = ScoreModel(backbone="none", sde="ouve", condition="noisy", sde_input="noisy", n_fft=1022, hop_length=160, num_frames=100)
+    with pytest.raises(ValueError, match="multiple of 64"):
+        m.train_step({"clean": torch.zeros(1, 20000), "perturbed": torch.zeros(1, 20000)})

@@ -82,7 +82,7 @@ def test_wav_write_subtypes(tmp_path):
     np.testing.assert_array_equal(wavio.read_wav(str(tmp_path / "s.wav"))[0], st.astype(np.float64))
 
 
-@pytest.mark.parametrize("rate,n", [(48000, 9000), (16000, 6401), (44100, 4410), (24000, 3000)])
+@pytest.mark.parametrize("rate,n", [(48000, 9000), (16000, 6401), (44100, 4410), (44100, 147 * 37), (22050, 147 * 20), (24000, 3000)])
 def test_load_utterance_is_the_reference_loader(tmp_path, rate, n):
     """sf.read -> first channel -> librosa fft resampling -> peak normalisation, float64, then float32 (loadwav_dataset.py:90-120)."""
     from scipy.io import wavfile
@@ -91,7 +91,7 @@ def test_load_utterance_is_the_reference_loader(tmp_path, rate, n):
     wavfile.write(str(tmp_path / "x.wav"), rate, pcm)
     x = pcm[:, 0].astype(np.float64) / 32768.0
     if rate != 24000:
-        x = resample(x, int(np.ceil(len(x) * 24000 / rate)))
+        x = resample(x, int(np.ceil(len(x) * (24000 / rate))))     # librosa's order: the ratio is rounded first (147 * k samples -> one more)
     want = (x / np.max(np.abs(x)) * 0.8).astype(np.float32)
     got, sr = wavio.load_utterance(str(tmp_path / "x.wav"), 24000, True)
     assert sr == 24000 and got.dtype == np.float32 and got.shape == want.shape

@@ -121,10 +121,11 @@ template <> struct Mfma<float> {
 // ---------------------------------------------------------------------------------------------------------
 // GroupNorm statistics: producers add their per-channel partial sums into [B][C][2] 64-bit fixed-point totals (integer
 // atomics commute, so the result does not depend on the arrival order: bit-reproducible); consumers turn the totals of a
-// channel's group into the affine (a, b) of y = a x + b.  Scales: sums 2^-20, sums of squares 2^-12 per count - absolute
-// resolution far below fp32's on these magnitudes, range |sum| < 8e12, sum of squares < 2e15 per (item, channel).
+// channel's group into the affine (a, b) of y = a x + b.  Scales: 2^-20 per count for the sums and the sums of squares - a 64-pixel
+// partial sum of squares of activations around 1e-3 still holds ~70 counts (at round 2's 2^-12 it rounded to 0 and the variance of a
+// near-silent item was off by about eps); range |sum|, sum of squares < 8.7e12 per (item, channel): an rms of 5000 over a 512 x 640 map.
 // ---------------------------------------------------------------------------------------------------------
-constexpr float GN_SUM_SCALE = 1048576.0f, GN_SQ_SCALE = 4096.0f;
+constexpr float GN_SUM_SCALE = 1048576.0f, GN_SQ_SCALE = 1048576.0f;
 DEVI void gn_accumulate(long long* dst, float s, float q) {
     atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__float2ll_rn(s * GN_SUM_SCALE));
     atomicAdd(reinterpret_cast<unsigned long long*>(dst + 1), (unsigned long long)__float2ll_rn(q * GN_SQ_SCALE));
@@ -144,7 +145,7 @@ DEVI float2 gn_coef_of(const long long* __restrict__ st0, int C0, const long lon
     // v_rsq_f32 + one Newton step (relative error ~1e-7) instead of an fp64 sqrt and division (~100 instructions), so that every
     // workgroup of a consuming convolution can afford to finalise the GroupNorm of its own input channels
     const double mean = (double)S * (1.0 / 1048576.0) * (double)inv_n;
-    double var = (double)Q * (1.0 / 4096.0) * (double)inv_n - mean * mean;
+    double var = (double)Q * (1.0 / 1048576.0) * (double)inv_n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float v = (float)var + eps;
     float rstd = __builtin_amdgcn_rsqf(v);

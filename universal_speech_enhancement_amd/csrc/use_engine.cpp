@@ -1503,7 +1503,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
         std::vector<long long> hs((size_t)c->B * c->Cout * 2);
         if (hipMemcpy(hs.data(), stats, stats_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(USE_E_HIP, "copy back failed");
         for (size_t i = 0; i < hs.size(); i += 2) {
-            stats_host[i] = (float)((double)hs[i] / 1048576.0); stats_host[i + 1] = (float)((double)hs[i + 1] / 4096.0);
+            stats_host[i] = (float)((double)hs[i] / 1048576.0); stats_host[i + 1] = (float)((double)hs[i + 1] / 1048576.0);
         }
     }
     cleanup();

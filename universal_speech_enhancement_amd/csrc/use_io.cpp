@@ -218,7 +218,10 @@ int use_load_utterance(const char* path, int target_rate, int normalize, float**
     for (int64_t i = 0; i < frames; ++i) x[(size_t)i] = raw[(size_t)i * (size_t)ch];        // first channel (loadwav_dataset.py:93-94)
     free(raw);
     if (target_rate > 0 && target_rate != sr) {                                             // loadwav_dataset.py:95-98
-        const int64_t num = (int64_t)ceil((double)frames * (double)target_rate / (double)sr);   // librosa: ceil(len * ratio)
+        // librosa.resample: ratio = float(target_sr) / orig_sr first, then int(ceil(len * ratio)) - for 44.1 kHz-family rates and
+        // lengths that are multiples of 147 the rounded ratio gives one sample more than ceil(len * target / sr) would
+        const double ratio = (double)target_rate / (double)sr;
+        const int64_t num = (int64_t)ceil((double)frames * ratio);
         std::vector<double> y((size_t)num);
         resample_fft(x.data(), frames, num, y.data());
         x.swap(y);

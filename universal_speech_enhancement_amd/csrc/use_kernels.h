@@ -48,7 +48,7 @@ struct ConvArgs {
     const float* w4;        // [Cout][4]
     const float* b4;        // [Cout]
     void* out; int out_dtype;
-    long long* stats;       // or null: [B][Cout][2] fixed-point totals (sum * 2^20, sum of squares * 2^12) of the stored values,
+    long long* stats;       // or null: [B][Cout][2] fixed-point totals (sum * 2^20, sum of squares * 2^20) of the stored values,
                             // accumulated with 64-bit integer atomics (order-independent, hence deterministic); zeroed by the caller
     int B, H, W, Cout, ntaps;
     int stagger, stagger_lo, stagger_hi;   // conv_v5_kernel: workgroups [lo, hi) of the dispatch order start `stagger` x s_sleep(127) late
