@@ -33,6 +33,7 @@ import torch  # noqa: E402
 FLOP_PER_FRAME_NFE = 4.1657e9        # 2*MAC per padded frame per score evaluation (F=512)
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_TBPS = 8.0                  # HBM3E (MI355X_MICROARCH.md); ~6.3 TB/s is what a streaming copy reaches
 
 
 from universal_speech_enhancement_amd.testing.cpu import usable_cores  # noqa: E402
@@ -143,7 +144,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if torch.distributed.is_initialized():                  # (also at world size 1 under a launcher: same calls as the N-GPU run)
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -171,6 +172,19 @@ def main():
     tvec = torch.full((B,), 0.5, device=dev)
     eng.profile_score(x, Y, tvec)                                   # warm
     conv_ms, conv_flops, conv_bytes, conv_launches, total_ms = eng.profile_score(x, Y, tvec)
+    # the HBM-bound kernels of the same evaluation ("glue kernels individually: HBM-bound"): algorithmic bytes
+    # (every operand once) / duration between HIP events / 8 TB/s, per kernel class and map, averaged over the launches
+    hbm_kernels = []
+    groups = {}
+    for name, Hm, Wm, by, ms in eng.profile_aux():
+        groups.setdefault((name, Hm, Wm), []).append((by, ms))
+    for (name, Hm, Wm), v in sorted(groups.items(), key=lambda kv: (-kv[0][1] * kv[0][2], kv[0][0])):
+        if Hm * Wm < 256 * 320:                                     # the smaller maps are hidden behind the other sub-batch's convolutions
+            continue
+        by = sum(b for b, _ in v) / len(v); ms = sum(m for _, m in v) / len(v)
+        hbm_kernels.append({"kernel": name, "map": f"{Hm}x{Wm}", "launches_per_score": len(v), "algorithmic_bytes": round(by),
+                            "avg_ms": round(ms, 4), "achieved_GBps": round(by / (ms * 1e-3) / 1e9, 1),
+                            "frac": round(by / (ms * 1e-3) / (PEAK_HBM_TBPS * 1e12), 4)})
     peak = PEAK_FP32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS      # bf16 and fp16 MFMA share the dense peak
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
     # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), which cannot be
@@ -201,7 +215,8 @@ def main():
                 "launches_per_score": conv_launches, "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                 "algorithmic_gflop_per_launch": round(conv_flops / max(conv_launches, 1) / 1e9, 2),
                 "kernel_time_share_of_eager_score": round(conv_ms / total_ms, 3),   # of one un-pipelined evaluation (sub-batches back to back)
-                "whole_path_tflops_per_gpu": round(tflops_path, 1), "whole_path_frac": round(tflops_path / peak, 4)}
+                "whole_path_tflops_per_gpu": round(tflops_path, 1), "whole_path_frac": round(tflops_path / peak, 4),
+                "hbm_peak_TBps": PEAK_HBM_TBPS, "hbm_kernels": hbm_kernels}
 
     cfg_name = ("configs[1]" if (B, a.N, ncorr, a.precision, a.seconds) == (8, 30, 1, "bf16", 4.0) else
                 "configs[3]" if (B, a.N, ncorr, a.precision, a.seconds) == (16, 200, 1, "bf16", 4.0) else
@@ -224,7 +239,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd_np)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -156,6 +156,11 @@ int use_istft_back(const void* X, float* wav, int B, int L, int n_fft, int hop, 
  * Synchronises the stream. */
 int use_profile_score(use_handle* h, const void* x, const void* y, const float* t, void* out, use_stream_t stream,
                       double* conv_ms, double* conv_flops, double* conv_bytes, int* conv_launches, double* total_ms);
+/* The HBM-bound kernels of the same evaluation (FIR x2 resampling of the activation maps, pyramid-head convolutions, the input
+ * convolution), one record per launch in launch order: kernel class ("fir_up", "fir_down", "pyr_conv", "conv_in"), the map it read
+ * (H x W per item of the sub-batch), its algorithmic HBM bytes (every operand once) and its duration between HIP events.  Returns 0,
+ * 1 when `index` is past the last record of the most recent use_profile_score, negative on error. */
+int use_profile_aux(use_handle* h, int index, char* name, int name_cap, int* H, int* W, double* bytes, double* ms);
 /* Single-convolution harness for kernel bring-up and same-box A/B timing (no reference counterpart): builds one fused
  * implicit-GEMM 3x3 convolution (optional second channel-concat source C1, GroupNorm affine + SiLU on the input, bias +
  * time-embedding bias, fused 1x1 shortcut over XC0+XC1 channels, residual, GroupNorm partial sums) on deterministic

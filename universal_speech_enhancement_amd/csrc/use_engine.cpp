@@ -155,6 +155,9 @@ struct use_handle {
     static constexpr int SDE_MAX_B = 1024, SDE_BLOCKS = 128;
     // per-launch HIP-event profiling of the dominant conv kernel (use_profile_score)
     bool profile = false, profile_all = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_flops, prof_bytes; std::vector<char> prof_main;
+    // ... and of the HBM-bound kernels around it (FIR resampling, pyramid heads, input convolution): name, map, algorithmic bytes
+    struct AuxProf { std::string name; int H, W; double bytes; hipEvent_t e0, e1; double ms; };
+    std::vector<AuxProf> prof_aux;
     std::vector<std::string> prof_desc;
     // introspection
     bool dry = false;
@@ -441,6 +444,17 @@ struct Fwd {
         return a;
     }
 
+    // use_profile_score: HIP events around one launch of an HBM-bound kernel, with its algorithmic bytes (every operand once)
+    template <typename F> void timed_aux(const char* name, int Hm, int Wm, double bytes, F&& launch) {
+        if (!h->profile) { launch(); return; }
+        use_handle::AuxProf a{name, Hm, Wm, bytes, nullptr, nullptr, 0.0};
+        (void)hipEventCreate(&a.e0); (void)hipEventCreate(&a.e1);
+        (void)hipEventRecord(a.e0, s);
+        launch();
+        (void)hipEventRecord(a.e1, s);
+        h->prof_aux.push_back(a);
+    }
+
     // coefficient array for the consumers that cannot finalise the GroupNorm themselves (the FIR resampling kernels)
     float* gn_coef(const Act& a, const Act* a2, const GNW& g) {
         const int C = a.C + (a2 ? a2->C : 0);
@@ -498,6 +512,10 @@ struct Fwd {
             }
             char d[160]; snprintf(d, sizeof d, "%-28s H=%3d W=%3d Cin=%3d Cout=%3d taps=%d gn=%d res=%d sc=%d", w.wname.c_str(), a.H, a.W, w.cin, w.cout, w.ntaps, gn != nullptr, res != nullptr, w2 ? w2->cin : 0);
             h->prof_desc.push_back(d);
+        } else if (h->profile && (w.cout <= 8 || (a.dtype == DT_F32 && w.cin <= 8))) {
+            const double px = (double)B * a.H * a.W;
+            const double by = px * w.cin * dtype_size(a.dtype) + px * w.cout * dtype_size(out_dtype) * (res ? 2.0 : 1.0) + (double)w.ntaps * w.cin * w.cout * dtype_size(a.dtype);
+            timed_aux(w.cout <= 8 ? "pyr_conv" : "conv_in", a.H, a.W, by, [&] { launch_conv(p, s); });
         } else {
             launch_conv(p, s);
         }
@@ -517,8 +535,10 @@ struct Fwd {
             xr = new_act(x.C, H2, W2, dt, false);
             float* coef0 = gn_coef(x, skip, r.gn0);          // the resampling kernels take the GroupNorm as a coefficient array
             if (!h->dry) {
-                if (r.up) launch_fir_up2(x.p, dt, coef0, 1, hr.p, xr.p, B, x.H, x.W, x.C, s);
-                else      launch_fir_down2(x.p, dt, coef0, 1, hr.p, xr.p, B, x.H, x.W, x.C, s);
+                // reads the map once, writes the activated and the raw resampled copy
+                const double by = (double)B * x.H * x.W * x.C * dtype_size(dt) + 2.0 * B * H2 * W2 * x.C * dtype_size(dt);
+                if (r.up) timed_aux("fir_up", x.H, x.W, by, [&] { launch_fir_up2(x.p, dt, coef0, 1, hr.p, xr.p, B, x.H, x.W, x.C, s); });
+                else      timed_aux("fir_down", x.H, x.W, by, [&] { launch_fir_down2(x.p, dt, coef0, 1, hr.p, xr.p, B, x.H, x.W, x.C, s); });
             }
             hcur = conv(hr, nullptr, nullptr, 0, r.c0, temb, nullptr, 1.f, nullptr, nullptr, dt, true);
             sx0 = &xr; sx1 = nullptr;
@@ -1121,6 +1141,8 @@ int use_profile_score(use_handle* h, const void* x, const void* y, const float* 
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t t0, t1; HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
     h->profile = true; h->prof_events.clear(); h->prof_flops.clear(); h->prof_bytes.clear(); h->prof_desc.clear(); h->prof_main.clear();
+    for (auto& a : h->prof_aux) { if (a.e0) (void)hipEventDestroy(a.e0); if (a.e1) (void)hipEventDestroy(a.e1); }
+    h->prof_aux.clear();
     const bool verbose = getenv("USE_HIP_PROFILE_VERBOSE") != nullptr;
     h->profile_all = verbose;                                 // verbose: also list the conv_v2_kernel launches
     HIPCHK(hipEventRecord(t0, s));
@@ -1136,6 +1158,10 @@ int use_profile_score(use_handle* h, const void* x, const void* y, const float* 
         if (verbose) fprintf(stderr, "[use_profile] %s  %8.3f ms  %7.1f TFLOP/s\n", h->prof_desc[i].c_str(), e, h->prof_flops[i] / e / 1e9);
         (void)hipEventDestroy(h->prof_events[i].first); (void)hipEventDestroy(h->prof_events[i].second);
     }
+    for (auto& a : h->prof_aux) {
+        float e = 0.f; HIPCHK(hipEventElapsedTime(&e, a.e0, a.e1));
+        a.ms = e; (void)hipEventDestroy(a.e0); (void)hipEventDestroy(a.e1); a.e0 = a.e1 = nullptr;
+    }
     float tot = 0.f; HIPCHK(hipEventElapsedTime(&tot, t0, t1));
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     if (conv_ms) *conv_ms = ms;
@@ -1145,6 +1171,15 @@ int use_profile_score(use_handle* h, const void* x, const void* y, const float* 
     if (total_ms) *total_ms = tot;
     h->profile_all = false;
     h->prof_events.clear(); h->prof_flops.clear(); h->prof_bytes.clear(); h->prof_main.clear();
+    return USE_OK;
+}
+
+int use_profile_aux(use_handle* h, int index, char* name, int name_cap, int* H, int* W, double* bytes, double* ms) {
+    if (!h) return fail(USE_E_INVALID, "null handle");
+    if (index < 0 || index >= (int)h->prof_aux.size()) return 1;          // past the end (not an error: the caller iterates)
+    const auto& a = h->prof_aux[(size_t)index];
+    if (name && name_cap > 0) { strncpy(name, a.name.c_str(), (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+    if (H) *H = a.H; if (W) *W = a.W; if (bytes) *bytes = a.bytes; if (ms) *ms = a.ms;
     return USE_OK;
 }
 

@@ -17,11 +17,15 @@ import torch.distributed as dist
 
 
 def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
-    """(rank, world_size, local_rank) from torchrun's environment; initialises the default group if needed."""
+    """(rank, world_size, local_rank) from torchrun's environment; initialises the default group if needed.  Under a launcher
+    (RANK and WORLD_SIZE set) the group is created at world size 1 as well, so that the one-GPU run of a launched job goes
+    through the same RCCL calls - communicator creation with ``device_id``, the weight broadcast, the MAX all-reduce - as
+    the N-GPU run; a plain ``python bench.py`` (no launcher environment) stays without a process group."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if (world > 1 or launched) and not dist.is_initialized():
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -49,7 +53,7 @@ def shard_list(items: Sequence, rank: int, world: int) -> List:
 
 def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     """In-place broadcast of a contiguous byte tensor (the packed weights) from ``src`` to every rank."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():                               # (world size 1 included: the call path of the N-GPU run)
         dist.broadcast(blob, src=src)
     return blob
 
@@ -64,12 +68,12 @@ def broadcast_weights(engine, state_dict=None, src: int = 0):
     else:
         engine.alloc_weight_blob()
     broadcast_blob(engine.weight_blob(), src=src)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         torch.cuda.synchronize()
 
 
 def max_over_ranks(value: float, device=None) -> float:
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -248,6 +248,19 @@ class HipScoreEngine:
                                        C.byref(ms), C.byref(fl), C.byref(by), C.byref(n), C.byref(tot)), "use_profile_score")
         return ms.value, fl.value, by.value, n.value, tot.value
 
+    def profile_aux(self):
+        """HBM-bound kernels of the last ``profile_score``: [(kernel class, H, W, algorithmic bytes, ms)] in launch order."""
+        out, i = [], 0
+        name = C.create_string_buffer(32)
+        H, W, by, ms = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        while True:
+            rc = self.L.use_profile_aux(self.h, i, name, 32, C.byref(H), C.byref(W), C.byref(by), C.byref(ms))
+            if rc == 1:
+                return out
+            check(rc, "use_profile_aux")
+            out.append((name.value.decode(), H.value, W.value, by.value, ms.value))
+            i += 1
+
     def set_sampler(self, N, predictor="reverse_diffusion", corrector="none", corrector_steps=1, snr=0.5, t_eps=3e-2,
                     use_graph=True):
         key = (self.plan_shape, N, predictor, corrector, corrector_steps, float(snr), float(t_eps), bool(use_graph))
