@@ -174,6 +174,37 @@ typedef struct use_conv_case {
     int variant, iters;
 } use_conv_case;
 int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, double* ms_avg, double* flops);
+/* ---- single operators of the path on caller-owned device tensors (NHWC: [B][H][W][C], C contiguous) with host fp32 weights.
+ * Test / bring-up surface: the per-operator golden vectors of the reference reach the HIP kernels through these.
+ * use_op_conv: out = ((conv3x3|1x1(act(a x + b)) + conv1x1(x0|x1) + bias + temb[b]) + res) * out_scale, exactly the fused operator of the
+ *   res-block (ResnetBlockBigGANpp, layerspp.py:282-314); channel counts are multiples of 32 (zero-pad smaller ones); `w` is the
+ *   reference's [Cout][Cin][3][3] (ntaps 9) or [Cout][Cin] (ntaps 1) tensor, `w2` [Cout][XC]; coef = GroupNorm folded to (a, b) per
+ *   (item, channel) or null; stats (zeroed by the caller) receives the fixed-point GroupNorm totals of the output.  variant: 0 = the
+ *   library's dispatcher, 1 generic, 2 conv_v2, 4 conv_v4, 7 conv_sk, 8 conv_v7.  Synchronises the stream.
+ * use_op_fir: upsample_2d / downsample_2d with the [1,3,3,1] kernel (up_or_down_sampling.py:202-264); out_act = FIR(act(a x + b)),
+ *   out_raw = FIR(x) (either may be null).
+ * use_op_attention: softmax(q k^T / sqrt(C)) v per item (AttnBlockpp core, layerspp.py:84-88), q/k/v/out [B][N][C].
+ * use_op_gn_finalize: GroupNorm totals (as accumulated in `stats`) of up to two concatenated sources -> coef[b][c] = (a, b). */
+typedef struct use_conv_op {
+    int B, H, W, C0, C1, Cout, XC0, XC1, ntaps, act, dtype, out_dtype, variant;
+    const void *src0, *src1;
+    const float* coef;
+    const float* w;
+    const float* bias;
+    const float* temb;
+    const void *x0, *x1;
+    const float* w2;
+    const void* res;
+    float out_scale;
+    void* out;
+    long long* stats;
+} use_conv_op;
+int use_op_conv(const use_conv_op* c, use_stream_t stream);
+int use_op_fir(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B, int H, int W, int C, int up,
+               use_stream_t stream);
+int use_op_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int N, int C, use_stream_t stream);
+int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta, int groups,
+                       int hw, float eps, float* coef, int B, use_stream_t stream);
 /* ---- wire formats either side of the path, host functions: no device, no handle ----
  * use_wav_read: RIFF/WAVE (PCM 8/16/24/32-bit, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE) -> interleaved float64 frames scaled like
  *   libsndfile's sf.read (integer PCM / 2^(bits-1)); *samples is malloc'ed, release it with use_free.

@@ -3,10 +3,11 @@
 Tolerances (relative to the reference tensor's max magnitude unless stated):
   fp32 storage  : one score evaluation  <= 5e-4   (measured 3e-6 .. 5e-5)
                   whole sampler, waveform <= 2e-3
-  bf16 storage  : one score evaluation  <= 6e-2   (measured ~2e-2; CPU bf16-autocast of the reference: 2.5e-2)
-                  whole sampler, waveform <= 1.5e-1 (stochastic-sampler error compounding, N<=5)
-  fp16 storage  : one score evaluation  <= 1e-2   (10-bit mantissa: 8x tighter than bf16)
-                  whole sampler, waveform <= 3e-2
+  16-bit bounds are 2x the measured error (each test prints it: pytest -s, "[measured]"):
+  bf16 storage  : one score evaluation  <= 3.7e-2 (measured 1.8e-2; CPU bf16-autocast of the reference: 2.5e-2)
+                  whole sampler, waveform <= 2.4e-2 (measured 1.2e-2)
+  fp16 storage  : one score evaluation  <= 4.2e-3 (measured 2.0e-3: 10-bit mantissa, 8x tighter than bf16)
+                  whole sampler, waveform <= 4.2e-3 (measured 2.1e-3)
 """
 import os
 
@@ -27,6 +28,12 @@ pytestmark = pytest.mark.gpu
 def _relmax(a, b):
     a, b = torch.as_tensor(a).cpu(), torch.as_tensor(b).cpu()
     return float((a - b).abs().max() / b.abs().max())
+
+
+def _check(err, tol, *tag):
+    """Assert with the measured error on record (pytest -s): the 16-bit bounds below are 2x these printed values."""
+    print("[measured]", *tag, f"{err:.3g} (bound {tol:g})")
+    assert err < tol, (tag, err, tol)
 
 
 @pytest.fixture(scope="module")
@@ -56,17 +63,17 @@ def _score_model(sd_np, precision, corrector="langevin", use_graph=True):
     return m
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", 6e-2), ("fp16", 1e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", 3.7e-2), ("fp16", 4.2e-3)])   # 16-bit: 2x measured (0.0183 / 0.0021)
 def test_score_matches_reference_golden(golden_dir, engines, prec, tol):
     g = dict(np.load(os.path.join(golden_dir, "forward_large.npz")))
     x = torch.from_numpy(g["x"]).cuda()
     for tag in ("a", "b"):
         out = engines[prec].score(x[:, 0:1].contiguous(), x[:, 1:2].contiguous(), torch.from_numpy(g["t_" + tag]).cuda())
         err = _relmax(out, -torch.from_numpy(g["out_" + tag]))        # library returns score = -net
-        assert err < tol, (prec, tag, err)
+        _check(err, tol, "score vs forward_large", prec, tag)
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", 6e-2), ("fp16", 1e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", 3.7e-2), ("fp16", 4.2e-3)])   # 16-bit: 2x measured (0.0183 / 0.0021)
 def test_score_golden_with_wide_tile_kernel_forced(golden_dir, engines, prec, tol):
     """conv_v4_kernel is normally reserved for maps of >= 128 workgroups per image; force it onto the golden-vector shapes."""
     from universal_speech_enhancement_amd.hip_engine import set_option
@@ -78,12 +85,12 @@ def test_score_golden_with_wide_tile_kernel_forced(golden_dir, engines, prec, to
     finally:
         set_option("conv_v4_min_blocks", 128)
     err = _relmax(out, -torch.from_numpy(g["out_a"]))
-    assert err < tol, (prec, err)
+    _check(err, tol, "score vs forward_large, conv_v4 forced", prec)
     with pytest.raises(Exception):
         set_option("no_such_option", 1)
 
 
-@pytest.mark.parametrize("prec,tol,tol_wav", [("fp32", 5e-4, 2e-3), ("bf16", 6e-2, 1.5e-1)])
+@pytest.mark.parametrize("prec,tol,tol_wav", [("fp32", 5e-4, 2e-3), ("bf16", 3.7e-2, 6e-2)])   # bf16: 2x measured (0.0179 / 0.0294)
 def test_lsgan_refine_generator_matches_reference(golden_dir, prec, tol, tol_wav):
     """NCSNpp(discriminative=True) through the backbone interface and NCSNPP_Wrapper / GANModule.predict_step
     through the batch-dict contract, against outputs of the reference itself."""
@@ -94,18 +101,18 @@ def test_lsgan_refine_generator_matches_reference(golden_dir, prec, tol, tol_wav
     w = NCSNPP_Wrapper(n_fft=1022, hop_length=160, num_frames=480, precision=prec)
     missing, unexpected = w.net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True), None
     out = w.net(torch.from_numpy(g["x"]).cuda())
-    assert _relmax(out, torch.from_numpy(g["out"])) < tol
+    _check(_relmax(out, torch.from_numpy(g["out"])), tol, "refine generator", prec)
     mod = GANModule(G=w)
     batch = mod.predict_step({"perturbed": torch.from_numpy(g["wav"]).cuda()})
     assert batch["fake"].shape == g["fake"].shape
-    assert _relmax(batch["fake"], torch.from_numpy(g["fake"])) < tol_wav
+    _check(_relmax(batch["fake"], torch.from_numpy(g["fake"])), tol_wav, "refine waveform", prec)
     with pytest.raises(UseHipError):
         w.net(torch.from_numpy(g["x"]))                       # CPU tensors: no fallback
     with pytest.raises(ValueError):
         w.net(torch.from_numpy(g["x"]).cuda().repeat(1, 2, 1, 1))   # a discriminative network takes Y alone
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", 5.3e-2)])   # bf16: 2x measured (0.0261)
 def test_refine_generator_long_sequence_attention(prec, tol):
     """T' = 128: the bottleneck of the 4-level refine generator is 64 x 16 = 1024 tokens, which takes the GEMM form of the
     attention core (scores and P.V as implicit GEMMs on conv_kernel + row softmax).  Against the CPU oracle."""
@@ -118,7 +125,7 @@ def test_refine_generator_long_sequence_attention(prec, tol):
     net = NCSNpp(discriminative=True, precision=prec)
     net.load_state_dict(sd, strict=True)
     out = net(Y.cuda())
-    assert _relmax(out, ref) < tol, _relmax(out, ref)
+    _check(_relmax(out, ref), tol, "refine generator, 1024-token attention", prec)
 
 
 def test_packed_weight_file_round_trip(tmp_path, golden_dir, engines, sd_np):
@@ -338,12 +345,11 @@ def test_fused_sampler_fp32_matches_reference_end_to_end(golden_dir, sd_np):
     assert torch.equal(out_graph, out_eager), "hipGraph replay must be bit-identical to eager launches"
 
 
-@pytest.mark.parametrize("prec,tol", [("bf16", 1.5e-1), ("fp16", 3e-2)])
+@pytest.mark.parametrize("prec,tol", [("bf16", 2.4e-2), ("fp16", 4.2e-3)])   # 2x measured (0.0117 / 0.0021)
 def test_fused_sampler_16bit_end_to_end_tolerance(golden_dir, sd_np, prec, tol):
     out, ref = _e2e(golden_dir, "sample_e2e.npz", sd_np, prec, True)
     err = _relmax(out, ref)
-    print(f"[e2e {prec}] waveform rel-max {err:.3e}")
-    assert err < tol
+    _check(err, tol, "sample_e2e waveform", prec)
 
 
 def test_cfg1_plumbing_config_matches_reference(golden_dir, sd_np):
@@ -648,7 +654,7 @@ def test_sample_with_device_stft_equals_torch_stft_path(golden_dir, sd_np):
 
 
 @pytest.mark.parametrize("name,arch,backbone", [("12m", tw.SMALL12M, "ncsnpp12M"), ("6m", tw.SMALL6M, "ncsnpp6M")])
-@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", 6e-2), ("fp16", 1e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", 3.7e-2), ("fp16", 4.2e-3)])   # 16-bit: 2x measured (0.0183 / 0.0021)
 def test_nf96_variants_match_reference(golden_dir, name, arch, backbone, prec, tol):
     """NCSNpp12M / NCSNpp6M (nf = 96: 96 / 192 / 288-channel convolutions take the 32-channel-chunk kernels; 24 x 4, 32 x 6
     and 32 x 9 GroupNorm groups; 96-channel attention) through the backbone registry, against outputs of the reference."""
@@ -660,7 +666,7 @@ def test_nf96_variants_match_reference(golden_dir, name, arch, backbone, prec, t
     x = torch.from_numpy(tnoise.complex_normal(int(g["x_seed"]), "small_x", (2, 2, 512, 64))) * 0.5
     out = net(x.cuda(), torch.from_numpy(g["t"]).cuda())
     err = _relmax(out, g["out"])
-    assert err < tol, (name, prec, err)
+    _check(err, tol, name, prec)
 
 
 @pytest.mark.parametrize("sde_input", ["noisy", "denoised"])
@@ -724,9 +730,9 @@ def test_condition_both_matches_reference(golden_dir, sde_input):
                                       corrector_steps=1, conditioning=[Y, Yd], noise=draws,
                                       score_fn=lambda x, t, score_conditioning=None, sde_input=None: m(x, t, score_conditioning, sde_input))()
     assert _relmax(m._waveform(seam, 9600), out[key]) < 1e-4
-    for prec, tol in (("bf16", 0.15), ("fp16", 0.03)):
+    for prec, tol in (("bf16", 3.1e-2), ("fp16", 3.8e-3)):        # 2x measured (0.0151 / 0.0019)
         o16 = model(prec).sample(dict(batch), N=int(g["N"]), corrector_steps=1, snr=0.5, noise=draws)
-        assert _relmax(o16[key], out[key]) < tol, prec
+        _check(_relmax(o16[key], out[key]), tol, "denoised-condition sampler", key, prec)
     with pytest.raises(NotImplementedError):
         m.sample({"perturbed": batch["perturbed"]}, N=1)                    # condition="both" without batch["fake"]
 

@@ -34,6 +34,12 @@ class UseConvCase(C.Structure):
                                        "dtype", "variant", "iters")]
 
 
+class UseConvOp(C.Structure):
+    _fields_ = ([(k, C.c_int) for k in ("B", "H", "W", "C0", "C1", "Cout", "XC0", "XC1", "ntaps", "act", "dtype", "out_dtype", "variant")] +
+                [(k, C.c_void_p) for k in ("src0", "src1", "coef", "w", "bias", "temb", "x0", "x1", "w2", "res")] +
+                [("out_scale", C.c_float), ("out", C.c_void_p), ("stats", C.c_void_p)])
+
+
 class UseHipError(RuntimeError):
     pass
 
@@ -80,6 +86,10 @@ SYMBOLS = {
     "use_profile_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double)]),
     "use_timesteps": (_i, [_i, _f, C.POINTER(_f)]),
     "use_conv_bench": (_i, [C.POINTER(UseConvCase), _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "use_op_conv": (_i, [C.POINTER(UseConvOp), _vp]),
+    "use_op_fir": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "use_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "use_op_gn_finalize": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _i, _vp]),
     "use_wav_read": (_i, [C.c_char_p, C.POINTER(C.POINTER(C.c_double)), C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),
     "use_wav_write": (_i, [C.c_char_p, _vp, _i64, _i, _i, _i]),
     "use_resample_fft": (_i, [_vp, _i64, _i64, _vp]),

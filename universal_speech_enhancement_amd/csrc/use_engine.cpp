@@ -1545,6 +1545,85 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
     return rc;
 }
 
+// ---- single operators on caller-owned device tensors (NHWC) with host fp32 weights: the kernels of the path one at a time, so that
+// the per-operator golden vectors of the reference (tests/golden/fir.npz, resblock_*.npz, attn.npz) reach the HIP code itself ----
+int use_op_conv(const use_conv_op* c, use_stream_t stream) {
+    if (!c || c->B < 1 || c->H < 1 || c->W < 1 || c->C0 < 1 || c->Cout < 1 || !c->src0 || !c->w || !c->out) return fail(USE_E_INVALID, "use_op_conv: bad argument");
+    const int dt = c->dtype, odt = c->out_dtype;
+    if ((dt != DT_F32 && dt != DT_BF16 && dt != DT_F16) || (odt != DT_F32 && odt != DT_BF16 && odt != DT_F16)) return fail(USE_E_INVALID, "use_op_conv: bad dtype");
+    const int Cin = c->C0 + c->C1, XC = c->XC0 + c->XC1, ntaps = c->ntaps == 1 ? 1 : 9;
+    if (Cin % 32 != 0 || XC % 32 != 0 || (c->C1 && c->C0 % 32) || (c->XC1 && c->XC0 % 32)) return fail(USE_E_INVALID, "use_op_conv: channel counts must be multiples of 32 (zero-pad)");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t es = dtype_size(dt);
+    ConvW w; w.cin = Cin; w.cout = c->Cout; w.ntaps = ntaps; w.w_dtype = dt; w.cin_src = Cin; w.cout_src = c->Cout;
+    w.cout_pad = c->Cout <= 32 ? 32 : (c->Cout + 127) / 128 * 128;
+    ConvW w2 = w; w2.cin = XC; w2.cin_src = XC; w2.ntaps = 1;
+    std::vector<void*> bufs;
+    auto dalloc = [&](size_t bytes) -> void* { void* q = nullptr; if (hipMalloc(&q, bytes) != hipSuccess) return nullptr; bufs.push_back(q); return q; };
+    auto cleanup = [&]() { for (void* q : bufs) (void)hipFree(q); };
+    const size_t wbytes = (size_t)ntaps * w.cout_pad * Cin * es, w2bytes = (size_t)w2.cout_pad * std::max(XC, 1) * es;
+    const bool slab = ntaps == 9 && w.cout_pad % 128 == 0 && Cin % conv_v4_chunk(dt) == 0;
+    const bool slab2 = XC > 0 && XC % conv_v4_chunk(dt) == 0 && w2.cout_pad % 128 == 0;
+    char* dw = (char*)dalloc(wbytes); char* dwb = slab ? (char*)dalloc(wbytes) : nullptr;
+    char* dw2 = XC ? (char*)dalloc(w2bytes) : nullptr; char* dw2b = slab2 ? (char*)dalloc(w2bytes) : nullptr;
+    float* dbias = (float*)dalloc((size_t)w.cout_pad * 4);
+    if (!dw || !dbias || (slab && !dwb) || (XC && !dw2) || (slab2 && !dw2b)) { cleanup(); return fail(USE_E_NOMEM, "use_op_conv: allocation failed"); }
+    {
+        std::vector<char> hp(wbytes), hpb(slab ? wbytes : 0);
+        pack_conv_raw(c->w, w, hp.data(), slab ? hpb.data() : nullptr);
+        (void)hipMemcpy(dw, hp.data(), wbytes, hipMemcpyHostToDevice);
+        if (slab) (void)hipMemcpy(dwb, hpb.data(), wbytes, hipMemcpyHostToDevice);
+        if (XC) {
+            if (!c->w2 || !c->x0) { cleanup(); return fail(USE_E_INVALID, "use_op_conv: shortcut without weights / input"); }
+            std::vector<char> hq(w2bytes), hqb(slab2 ? w2bytes : 0);
+            pack_conv_raw(c->w2, w2, hq.data(), slab2 ? hqb.data() : nullptr);
+            (void)hipMemcpy(dw2, hq.data(), w2bytes, hipMemcpyHostToDevice);
+            if (slab2) (void)hipMemcpy(dw2b, hqb.data(), w2bytes, hipMemcpyHostToDevice);
+        }
+        std::vector<float> hb((size_t)w.cout_pad, 0.f);
+        if (c->bias) memcpy(hb.data(), c->bias, (size_t)c->Cout * 4);
+        (void)hipMemcpy(dbias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+    }
+    ConvArgs a{};
+    a.B = c->B; a.H = c->H; a.W = c->W; a.Cout = c->Cout; a.ntaps = ntaps; a.in_dtype = dt; a.out_dtype = odt;
+    a.src0 = c->src0; a.src1 = c->C1 ? c->src1 : nullptr; a.C0 = c->C0; a.C1 = c->C1; a.coef = c->coef; a.act = c->act;
+    a.w = dw; a.wb = dwb; a.cout_pad = w.cout_pad;
+    a.x0 = XC ? c->x0 : nullptr; a.x1 = c->XC1 ? c->x1 : nullptr; a.XC0 = c->XC0; a.XC1 = c->XC1; a.w2 = dw2; a.w2b = dw2b;
+    a.bias = dbias; a.temb = c->temb; a.temb_bstride = c->Cout; a.res = c->res; a.out_scale = c->out_scale;
+    a.out = c->out; a.stats = c->stats;
+    int rc = USE_OK;
+    switch (c->variant) {
+        case 0: launch_conv(a, s); break;
+        case 1: launch_conv_generic(a, s); break;
+        case 2: if (!conv_v2_eligible(a)) rc = fail(USE_E_INVALID, "conv_v2 cannot run this case"); else launch_conv_v2(a, s); break;
+        case 4: if (!slab || (XC && !slab2) || a.H % 16 || a.W % 32 || dt != odt) rc = fail(USE_E_INVALID, "conv_v4 cannot run this case"); else launch_conv_v4(a, s); break;
+        case 7: if (!conv_sk_eligible(a)) rc = fail(USE_E_INVALID, "conv_sk cannot run this case"); else launch_conv_sk(a, s); break;
+        case 8: if (!conv_v7_supports(a)) rc = fail(USE_E_INVALID, "conv_v7 cannot run this case"); else { conv_v7_prepare(a.Cout, dt); launch_conv_v7(a, s); } break;
+        default: rc = fail(USE_E_INVALID, "use_op_conv: unknown variant %d", c->variant);
+    }
+    if (hipStreamSynchronize(s) != hipSuccess && rc == USE_OK) rc = fail(USE_E_HIP, "use_op_conv: %s", hipGetErrorString(hipGetLastError()));
+    cleanup();
+    return rc;
+}
+int use_op_fir(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B, int H, int W, int C, int up,
+               use_stream_t stream) {
+    if (!src || (!out_act && !out_raw) || B < 1 || H < 1 || W < 1 || C < 1) return fail(USE_E_INVALID, "use_op_fir: bad argument");
+    if (up) launch_fir_up2(src, dtype, coef, act, out_act, out_raw, B, H, W, C, (hipStream_t)stream);
+    else    launch_fir_down2(src, dtype, coef, act, out_act, out_raw, B, H, W, C, (hipStream_t)stream);
+    return USE_OK;
+}
+int use_op_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int N, int C, use_stream_t stream) {
+    if (!q || !k || !v || !out || B < 1 || N < 1 || C < 1) return fail(USE_E_INVALID, "use_op_attention: bad argument");
+    launch_attention(q, k, v, out, dtype, B, N, C, (hipStream_t)stream);
+    return USE_OK;
+}
+int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta, int groups,
+                       int hw, float eps, float* coef, int B, use_stream_t stream) {
+    if (!st0 || !gamma || !beta || !coef || C0 < 1 || groups < 1 || (C0 + C1) % groups) return fail(USE_E_INVALID, "use_op_gn_finalize: bad argument");
+    launch_gn_finalize(st0, C0, C1 ? st1 : nullptr, C1, gamma, beta, groups, hw, eps, coef, B, (hipStream_t)stream);
+    return USE_OK;
+}
+
 int use_debug_tensor(use_handle* h, const char* name, void** dev_ptr, int* dims4, int* dtype) {
     if (!h || !name) return fail(USE_E_INVALID, "null argument");
     auto it = h->debug.find(name);
