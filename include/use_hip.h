@@ -149,6 +149,11 @@ int use_stft_fwd(const float* wav, void* Y, int B, int L, int n_fft, int hop, co
 int use_istft_back(const void* X, float* wav, int B, int L, int n_fft, int hop, const float* window, int Tpad, float factor,
                    float exponent, use_stream_t s);
 
+/* Counters of a handle: "graph_captures" (segments of the sampling loop captured so far), "plans_built", "plan_cache_hits",
+ * "plans_parked".  A handle keeps the plans - workspace, state, time-embedding tables, captured graphs - of the most recently used
+ * (B, T') shapes (use_set_option("plan_cache", k), default 4 besides the current one): use_plan of a parked shape costs nothing and
+ * its graphs replay as they are. */
+int use_get_stat(use_handle* h, const char* name, long long* value);
 /* Introspection for tests / profiling */
 /* One eager score evaluation with a HIP-event pair around every launch of the dominant kernel (conv_v4_kernel, the
  * wide-tile implicit-GEMM 3x3 convolution of the large feature maps): summed kernel time, their algorithmic FLOPs and

@@ -82,6 +82,7 @@ SYMBOLS = {
     "use_sde_corrector": (_i, [_vp, _i, _f, _f, _i, _vp, _vp, _vp, _u64, _vp, _vp, _i64, _vp]),
     "use_debug_tensor": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)]),
     "use_flops_per_score": (C.c_double, [_vp]),
+    "use_get_stat": (_i, [_vp, C.c_char_p, C.POINTER(C.c_longlong)]),
     "use_profile_aux": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "use_profile_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double)]),
     "use_timesteps": (_i, [_i, _f, C.POINTER(_f)]),

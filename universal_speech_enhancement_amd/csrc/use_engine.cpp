@@ -150,6 +150,13 @@ struct use_handle {
     int debug_B = 0;
     std::vector<hipGraphExec_t> graph_exec[2];           // [0]: device RNG, [1]: injected noise; one graph per segment of steps
     hipGraphExec_t score_graph = nullptr;
+    // plan cache: a predict run over files of different lengths alternates between a handful of (B, T') shapes; the plans of the
+    // most recently used ones are parked here - workspace, state buffers, time-embedding tables and the captured graphs with the
+    // addresses they hold - so that a shape that returns is neither re-planned nor re-captured.  use_set_option("plan_cache", k).
+    struct PlanState;
+    std::vector<PlanState*> plan_cache;          // most recently used last
+    long long opt_gen_at_plan = -1;              // g_opt_gen when the current plan was built
+    long long n_graph_captures = 0, n_plans_built = 0, n_plan_cache_hits = 0;
     // scratch for the stand-alone use_sde_* entry points (independent of weights / plan)
     char* sde_buf = nullptr; unsigned long long* sde_rng = nullptr; float* sde_step = nullptr; float* sde_partial = nullptr;
     static constexpr int SDE_MAX_B = 1024, SDE_BLOCKS = 128;
@@ -426,6 +433,10 @@ static int g_subbatch = 2;                       // use_set_option("subbatch", n
 static long g_gn_inline = 128L * 160L;
 static int g_stagger_level = 2;                  // use_set_option("stagger_level", l): the next sub-batch starts after level l
 
+__global__ __launch_bounds__(256) void zero16_kernel(uint4* __restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+}
+
 struct Fwd {
     use_handle* h; hipStream_t s;
     const float* tembias; int temb_bstride;      // [B or 1][dense_rows] (already offset to this sub-batch)
@@ -600,7 +611,13 @@ struct Fwd {
         const int L = c.n_levels, nrb = c.num_res_blocks, dt = H->act_dtype;
         arena->reset();
         st_arena->reset();
-        if (!H->dry && st_arena->base) (void)hipMemsetAsync(st_arena->base, 0, st_arena->cap, s);   // all GroupNorm totals of this evaluation
+        // all GroupNorm totals of this evaluation; a kernel, not hipMemsetAsync: a captured memset node of this (small) size does not
+        // clear the region again on the second replay of a graph that holds four or more evaluations (ROCm 7.2; seen as NaN from the
+        // second sampler call on for batches of 1-3 items, i.e. without the sub-batch split)
+        if (!H->dry && st_arena->base) {
+            const size_t n16 = st_arena->cap / 16;
+            hipLaunchKernelGGL(zero16_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 1024)), dim3(256), 0, s, (uint4*)st_arena->base, n16);
+        }
         if (primary) { H->flops = 0.0; H->debug.clear(); H->debug_B = B; }
         const int pcp = H->pcp;
         Act xin; xin.p = (void*)x4; xin.C = pcp; xin.H = c.n_freq; xin.W = H->T; xin.dtype = DT_F32;
@@ -622,7 +639,8 @@ struct Fwd {
                     Act o = resblock(hs.back(), nullptr, H->res[ri++]);
                     const CombineW& cb = H->combines[ci++];
                     if (!H->dry) {
-                        (void)hipMemsetAsync(o.stats, 0, (size_t)B * o.C * 2 * sizeof(long long), s);   // totals of the combined map
+                        hipLaunchKernelGGL(zero16_kernel, dim3((unsigned)(((size_t)B * o.C + 255) / 256)), dim3(256), 0, s, (uint4*)o.stats,
+                                           (size_t)B * o.C);                                             // totals of the combined map (16 bytes per channel)
                         launch_combine_add(o.p, o.dtype, (const float*)ipyr.p, W<float>(cb.w_off), W<float>(cb.b_off), o.stats, B,
                                            (long)o.H * o.W, o.C, s);
                     }
@@ -791,6 +809,54 @@ static void drop_graphs(use_handle* h) {
     if (h->score_graph) { (void)hipGraphExecDestroy(h->score_graph); h->score_graph = nullptr; }
 }
 
+// everything of the handle that belongs to ONE plan (the current plan lives in the handle's own fields)
+#define USE_PLAN_FIELDS(X)                                                                                            \
+    X(B) X(T) X(nsub) X(arena) X(arena_alloc) X(persist) X(persist_bytes) X(persist_alloc) X(x4) X(silu_temb) X(tembias) X(t_dev) \
+    X(Y) X(X) X(Xmean) X(score) X(xin) X(cond_buf) X(cond2_buf) X(Cond) X(lang_partial) X(lang_step) X(rng_state) X(lang_blocks)   \
+    X(sc) X(sampler_set) X(timesteps) X(ts_dev) X(temb_table) X(silu_table) X(noise_copy) X(noise_copy_bytes) X(score_graph)      \
+    X(debug) X(debug_B) X(opt_gen_at_plan)
+struct use_handle::PlanState {
+#define X(f) decltype(use_handle::f) f;
+    USE_PLAN_FIELDS(X)
+#undef X
+    int sub_B[MAX_SUB]; Arena sub_arena[MAX_SUB], st_arena[MAX_SUB];
+    std::vector<hipGraphExec_t> graph_exec[2];
+};
+static long long g_opt_gen = 0;                  // bumped by every use_set_option: plans built under other options are not reused
+static int g_plan_cache = 4;                     // plans kept besides the current one
+static void plan_stash(use_handle* h, use_handle::PlanState& p) {      // handle -> p; the handle's plan fields are left empty
+#define X(f) p.f = std::move(h->f);
+    USE_PLAN_FIELDS(X)
+#undef X
+    for (int i = 0; i < MAX_SUB; ++i) { p.sub_B[i] = h->sub_B[i]; p.sub_arena[i] = h->sub_arena[i]; p.st_arena[i] = h->st_arena[i]; }
+    for (int i = 0; i < 2; ++i) { p.graph_exec[i] = std::move(h->graph_exec[i]); h->graph_exec[i].clear(); }
+    h->B = h->T = 0; h->arena = Arena{}; h->arena_alloc = 0; h->persist = nullptr; h->persist_bytes = h->persist_alloc = 0;
+    h->ts_dev = h->temb_table = h->silu_table = nullptr; h->noise_copy = nullptr; h->noise_copy_bytes = 0; h->score_graph = nullptr;
+    h->sampler_set = false; h->timesteps.clear(); h->debug.clear();
+}
+static void plan_restore(use_handle* h, use_handle::PlanState& p) {    // p -> handle
+#define X(f) h->f = std::move(p.f);
+    USE_PLAN_FIELDS(X)
+#undef X
+    for (int i = 0; i < MAX_SUB; ++i) { h->sub_B[i] = p.sub_B[i]; h->sub_arena[i] = p.sub_arena[i]; h->st_arena[i] = p.st_arena[i]; }
+    for (int i = 0; i < 2; ++i) h->graph_exec[i] = std::move(p.graph_exec[i]);
+}
+static void plan_free(use_handle::PlanState* p) {
+    for (auto& v : p->graph_exec) for (auto g : v) if (g) (void)hipGraphExecDestroy(g);
+    if (p->score_graph) (void)hipGraphExecDestroy(p->score_graph);
+    if (p->arena.base) (void)hipFree(p->arena.base);
+    if (p->persist) (void)hipFree(p->persist);
+    if (p->temb_table) (void)hipFree(p->temb_table);
+    if (p->silu_table) (void)hipFree(p->silu_table);
+    if (p->ts_dev) (void)hipFree(p->ts_dev);
+    if (p->noise_copy) (void)hipFree(p->noise_copy);
+    delete p;
+}
+static void plan_cache_clear(use_handle* h) {                          // weights changed / handle destroyed: every parked plan is stale
+    for (auto* p : h->plan_cache) plan_free(p);
+    h->plan_cache.clear();
+}
+
 static int ensure_sde_scratch(use_handle* h) {
     if (!h) return fail(USE_E_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->device));
@@ -814,8 +880,19 @@ static int ensure_cap_stream(use_handle* h) {
 // ---------------------------------------------------------------------------------------------------------
 extern "C" {
 
+int use_get_stat(use_handle* h, const char* name, long long* value) {
+    if (!h || !name || !value) return fail(USE_E_INVALID, "null argument");
+    if (!strcmp(name, "graph_captures")) { *value = h->n_graph_captures; return USE_OK; }      // sampling-loop segments captured so far
+    if (!strcmp(name, "plans_built")) { *value = h->n_plans_built; return USE_OK; }
+    if (!strcmp(name, "plan_cache_hits")) { *value = h->n_plan_cache_hits; return USE_OK; }
+    if (!strcmp(name, "plans_parked")) { *value = (long long)h->plan_cache.size(); return USE_OK; }
+    return fail(USE_E_INVALID, "unknown statistic '%s'", name);
+}
+
 int use_set_option(const char* name, long long value) {
     if (!name) return fail(USE_E_INVALID, "option name is null");
+    ++g_opt_gen;                                               // plans built under the previous options are not reused
+    if (!strcmp(name, "plan_cache")) { g_plan_cache = (int)std::max(0LL, std::min(16LL, value)); return USE_OK; }   // parked plans per handle
     if (!strcmp(name, "subbatch")) { g_subbatch = (int)value; return USE_OK; }          // takes effect at the next use_plan
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
     if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
@@ -860,7 +937,7 @@ int use_destroy(use_handle* h) {
     if (!h) return USE_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    drop_graphs(h);
+    drop_graphs(h); plan_cache_clear(h);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     for (int i = 0; i < MAX_SUB; ++i) {
         if (h->aux_stream[i]) (void)hipStreamDestroy(h->aux_stream[i]);
@@ -911,7 +988,7 @@ int use_alloc_weight_blob(use_handle* h) {
     if (!h->blob) HIPCHK(hipMalloc((void**)&h->blob, h->blob_bytes));
     h->weights_ready = true;   // contents to be filled by the caller's broadcast
     h->sampler_set = false;    // the time-embedding table was built from the previous contents
-    drop_graphs(h);
+    drop_graphs(h); plan_cache_clear(h);
     return USE_OK;
 }
 
@@ -926,7 +1003,7 @@ int use_commit_weights(use_handle* h) {
     h->host_w.clear();
     h->weights_ready = true;
     h->sampler_set = false;    // the temb table depends on the weights
-    drop_graphs(h);
+    drop_graphs(h); plan_cache_clear(h);
     return USE_OK;
 }
 
@@ -1024,8 +1101,27 @@ int use_plan(use_handle* h, int B, int Tpad) {
     if (B < 1 || Tpad < 64 || Tpad % 64 != 0) return fail(USE_E_INVALID, "plan needs B >= 1 and T' a positive multiple of 64 (got B=%d T'=%d)", B, Tpad);
     if ((Tpad >> (h->cfg.n_levels - 1)) < 1) return fail(USE_E_INVALID, "T' too small for %d levels", h->cfg.n_levels);
     HIPCHK(hipSetDevice(h->device));
+    if (h->arena.base && h->B == B && h->T == Tpad && h->opt_gen_at_plan == g_opt_gen) return USE_OK;     // the current plan
     HIPCHK(hipDeviceSynchronize());
-    drop_graphs(h);
+    use_handle::PlanState* hit = nullptr;                     // the requested plan, if it is parked: taken out BEFORE the current one
+    for (size_t i = 0; i < h->plan_cache.size(); ++i) {       // goes in (else a cycle over capacity + 1 shapes would evict what it needs)
+        use_handle::PlanState* p = h->plan_cache[i];
+        if (p->B == B && p->T == Tpad && p->opt_gen_at_plan == g_opt_gen) { hit = p; h->plan_cache.erase(h->plan_cache.begin() + (long)i); break; }
+    }
+    if (h->arena.base) {                                      // park the current plan (with its graphs)
+        auto* p = new use_handle::PlanState();
+        plan_stash(h, *p);
+        if (g_plan_cache > 0 && p->opt_gen_at_plan == g_opt_gen) h->plan_cache.push_back(p); else plan_free(p);
+        while ((int)h->plan_cache.size() > g_plan_cache) { plan_free(h->plan_cache.front()); h->plan_cache.erase(h->plan_cache.begin()); }
+    }
+    if (hit) {
+        plan_restore(h, *hit);
+        delete hit;
+        ++h->n_plan_cache_hits;
+        return USE_OK;
+    }
+    ++h->n_plans_built;
+    h->opt_gen_at_plan = g_opt_gen;
     h->B = B; h->T = Tpad; h->sampler_set = false;
     // sub-batch pipelining (run_score): `subbatch` sub-batches of at least 2 items each
     h->nsub = std::max(1, std::min(std::min(g_subbatch, MAX_SUB), B / 2));
@@ -1198,6 +1294,7 @@ int use_set_sampler(use_handle* h, const use_sampler_config* sc) {
     if (sc->predictor < 0 || sc->predictor > 2 || sc->corrector < 0 || sc->corrector > 2) return fail(USE_E_INVALID, "unknown predictor/corrector id");
     if (sc->corrector != USE_CORR_NONE && sc->corrector_steps < 0) return fail(USE_E_INVALID, "negative corrector_steps");
     HIPCHK(hipSetDevice(h->device));
+    if (h->sampler_set && !memcmp(&h->sc, sc, sizeof *sc)) return USE_OK;       // unchanged (e.g. a parked plan taken back): tables and graphs stay
     HIPCHK(hipDeviceSynchronize());
     drop_graphs(h);
     h->sc = *sc;
@@ -1284,11 +1381,20 @@ int use_sample_cond2(use_handle* h, const void* y, const void* cond, const void*
                 hipGraphExec_t ge = nullptr;
                 HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
                 run_sampler(h, nz, h->cap_stream, i0, std::min(h->sc.N, i0 + per_seg));
-                HIPCHK(hipStreamEndCapture(h->cap_stream, &g));
-                hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+                // (nothing returns between begin and end: a failed launch invalidates the capture and surfaces here, with the
+                // stream out of capture mode either way)
+                hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+                if (e != hipSuccess || !g) {
+                    if (g) (void)hipGraphDestroy(g);
+                    (void)hipGetLastError();
+                    drop_graphs(h);
+                    return fail(USE_E_HIP, "capturing the sampling loop failed: %s", hipGetErrorString(e));
+                }
+                e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
                 (void)hipGraphDestroy(g);
                 if (e != hipSuccess) { drop_graphs(h); return fail(USE_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
                 h->graph_exec[gi].push_back(ge);
+                ++h->n_graph_captures;
             }
         }
         for (auto ge : h->graph_exec[gi]) HIPCHK(hipGraphLaunch(ge, s));

@@ -248,6 +248,12 @@ class HipScoreEngine:
                                        C.byref(ms), C.byref(fl), C.byref(by), C.byref(n), C.byref(tot)), "use_profile_score")
         return ms.value, fl.value, by.value, n.value, tot.value
 
+    def stat(self, name: str) -> int:
+        """A counter of the handle (``use_get_stat``): "graph_captures", "plans_built", "plan_cache_hits", "plans_parked"."""
+        v = C.c_longlong()
+        check(self.L.use_get_stat(self.h, name.encode(), C.byref(v)), "use_get_stat")
+        return int(v.value)
+
     def profile_aux(self):
         """HBM-bound kernels of the last ``profile_score``: [(kernel class, H, W, algorithmic bytes, ms)] in launch order."""
         out, i = [], 0
