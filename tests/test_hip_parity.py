@@ -902,3 +902,31 @@ def test_second_and_third_replay_of_a_small_batch_graph(engines, B):
     outs = [eng.sample(y, seed=21).clone() for _ in range(3)]
     assert all(torch.isfinite(torch.view_as_real(o)).all() for o in outs)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16", 1.0e-2), ("fp16", 9e-4)])      # 2x measured (4.9e-3 / 4.3e-4)
+def test_fused_attention_block_matches_the_oracle_block(golden_dir, engines, sd_np, prec, tol):
+    """attn_fused_kernel (GroupNorm -> q, k, v NIN -> softmax(q k^T / sqrt(C)) v -> NIN_3 -> (x + h) / sqrt(2) in one launch, MFMA
+    contractions; AttnBlockpp, layerspp.py:60-93) in isolation: the oracle's fp32 attention block applied to the block input the HIP
+    path itself produced (the `pre_attn` tap, 16-bit) against the fused kernel's `post_attn`; and against the unfused path
+    (three NIN launches, the VALU attention core, NIN_3) on the same input."""
+    from universal_speech_enhancement_amd.hip_engine import set_option
+    g = dict(np.load(os.path.join(golden_dir, "forward_large.npz")))
+    x = torch.from_numpy(g["x"]).cuda(); t = torch.from_numpy(g["t_b"]).cuda()
+    sd = no.to_torch(sd_np)
+    prefix = [k[:-len(".NIN_0.W")] for k in sd if k.endswith(".NIN_0.W")][0]
+    eng = engines[prec]
+    taps = {}
+    for fused in (1, 0):
+        set_option("attn_fused", fused)
+        try:
+            eng.plan(x.shape[0], x.shape[3])
+            eng.score(x[:, 0:1].contiguous(), x[:, 1:2].contiguous(), t)
+            taps[fused] = (eng.debug_tensor("pre_attn").permute(0, 3, 1, 2).cpu(), eng.debug_tensor("post_attn").permute(0, 3, 1, 2).cpu())
+        finally:
+            set_option("attn_fused", 1)
+    assert torch.equal(taps[0][0], taps[1][0])                                   # same block input either way
+    with torch.no_grad():
+        want = no.attn_block(taps[1][0], sd, prefix)
+    _check(_relmax(taps[1][1], want), tol, "fused attention block vs oracle block", prec)
+    _check(_relmax(taps[0][1], want), tol, "unfused attention block vs oracle block", prec)

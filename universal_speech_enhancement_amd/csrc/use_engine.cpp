@@ -431,6 +431,7 @@ static int g_subbatch = 2;                       // use_set_option("subbatch", n
 // finalize launch above: on the large maps thousands of workgroups would each redo the finalisation (measured slower), on the
 // small, latency-bound maps the saved launch is what counts.  use_set_option("gn_inline", pixels); 0: never inline
 static long g_gn_inline = 128L * 160L;
+static int g_attn_fused = 1;                     // use_set_option("attn_fused", 0): the unfused attention block (3 NIN, core, NIN_3)
 static int g_stagger_level = 2;                  // use_set_option("stagger_level", l): the next sub-batch starts after level l
 
 __global__ __launch_bounds__(256) void zero16_kernel(uint4* __restrict__ p, size_t n16) {
@@ -564,6 +565,19 @@ struct Fwd {
     // AttnBlockpp.forward (reference layerspp.py:77-93)
     Act attention(const Act& x, const AttnW& aw) {
         const int dt = h->act_dtype;
+        if (g_attn_fused && x.stats && attn_fused_eligible(dt, x.H * x.W, x.C)) {       // one launch, MFMA contractions (use_attn.hip)
+            Act o = new_act(x.C, x.H, x.W, dt, true);
+            h->flops += 4.0 * 2.0 * B * x.H * x.W * (double)x.C * x.C;                  // the four NIN, as the unfused path counts them
+            if (h->dry) return o;
+            AttnArgs a{};
+            a.x = x.p; a.out = o.p; a.N = x.H * x.W;
+            a.gn_st = x.stats; a.gn_gamma = W<float>(aw.gn.g_off); a.gn_beta = W<float>(aw.gn.b_off); a.gn_groups = std::min(x.C / 4, 32); a.gn_eps = 1e-6f;
+            a.wq = h->blob + aw.q.w_off; a.wk = h->blob + aw.k.w_off; a.wv = h->blob + aw.v.w_off; a.wo = h->blob + aw.o.w_off;
+            a.bq = W<float>(aw.q.b_off); a.bk = W<float>(aw.k.b_off); a.bv = W<float>(aw.v.b_off); a.bo = W<float>(aw.o.b_off);
+            a.stats = o.stats;
+            launch_attn_fused(a, dt, B, s);
+            return o;
+        }
         Act q = conv(x, nullptr, &aw.gn, 0, aw.q, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
         Act k = conv(x, nullptr, &aw.gn, 0, aw.k, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
         Act v = conv(x, nullptr, &aw.gn, 0, aw.v, nullptr, nullptr, 1.f, nullptr, nullptr, dt, false);
@@ -892,6 +906,7 @@ int use_get_stat(use_handle* h, const char* name, long long* value) {
 int use_set_option(const char* name, long long value) {
     if (!name) return fail(USE_E_INVALID, "option name is null");
     ++g_opt_gen;                                               // plans built under the previous options are not reused
+    if (!strcmp(name, "attn_fused")) { g_attn_fused = (int)value; return USE_OK; }
     if (!strcmp(name, "plan_cache")) { g_plan_cache = (int)std::max(0LL, std::min(16LL, value)); return USE_OK; }   // parked plans per handle
     if (!strcmp(name, "subbatch")) { g_subbatch = (int)value; return USE_OK; }          // takes effect at the next use_plan
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }

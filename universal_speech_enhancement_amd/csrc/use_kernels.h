@@ -140,6 +140,17 @@ void launch_temb_dense(const float* silu_temb, const float* W, const float* bias
 void launch_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int N, int C,
                       hipStream_t s);
 
+// The whole bottleneck attention block (GroupNorm -> q, k, v NIN -> softmax(q k^T / sqrt(C)) v -> NIN_3 -> (x + h) / sqrt(2)) in one
+// launch, every contraction on the matrix pipe (use_attn.hip): C = 256, N <= 96 tokens, 16-bit storage.  NIN weights [Cout][Cin].
+struct AttnArgs {
+    const void* x; void* out; int N;
+    const long long* gn_st; const float* gn_gamma; const float* gn_beta; int gn_groups; float gn_eps;
+    const void *wq, *wk, *wv, *wo; const float *bq, *bk, *bv, *bo;
+    long long* stats;        // GroupNorm totals of `out` (zeroed by the caller) or null
+};
+bool attn_fused_eligible(int dtype, int N, int C);
+void launch_attn_fused(const AttnArgs& a, int dtype, int B, hipStream_t s);
+
 // helpers of the long-sequence attention path (two implicit GEMMs on conv_kernel, see Fwd::attention)
 void launch_softmax_rows(void* x, int dtype, long rows, int cols, hipStream_t s);            // in place, over the last axis
 void launch_transpose_nc(const void* in, void* out, int dtype, int B, int N, int C, hipStream_t s);   // [B][N][C] -> [B][C][N]
