@@ -210,6 +210,24 @@ int use_op_fir(const void* src, int dtype, const float* coef, int act, void* out
 int use_op_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int N, int C, use_stream_t stream);
 int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta, int groups,
                        int hw, float eps, float* coef, int B, use_stream_t stream);
+/* ---- backward operators of one res-block (minimum slice of ScoreModel.train_step's gradients, reference
+ * model_wrapper.py:147-208 / SGMSE_module.py:46-54).  fp32 NHWC device tensors.  The data gradient of a convolution is use_op_conv
+ * itself on the flipped, transposed weights; these are the rest:
+ * use_op_wgrad:      dW[co][ci][tap] = alpha * sum dY[b,p,co] X[b,p+tap,ci] (reference weight layout), db[co] = alpha * sum dY (or null).
+ * use_op_gn_act_bwd: gradient of act(GroupNorm(groups, eps)(x)) (act: 0 none, 1 SiLU) against dy: dx (+ add_scale * add when add is
+ *                    given), dgamma, dbeta; `work`: 2 B (groups + C) floats of scratch.
+ * use_op_gn_act_fwd: y = act(GroupNorm(x)) (the operand of the following convolution's weight gradient, recomputed); work: 2 B groups floats.
+ * use_op_colsum:     out[b][c] = scale * sum_p x[b,p,c]            (the gradient reaching Dense_0's output)
+ * use_op_dense_bwd:  Dense_0(SiLU(temb)): g [B][Cout] -> dW [Cout][K], db [Cout], dtemb [B][K]. */
+int use_op_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
+                 use_stream_t stream);
+int use_op_gn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, int groups, float eps, int act, const float* add,
+                      float add_scale, int B, int HW, int C, float* work, float* dx, float* dgamma, float* dbeta, use_stream_t stream);
+int use_op_gn_act_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, int act, int B, int HW, int C, float* work,
+                      float* y, use_stream_t stream);
+int use_op_colsum(const float* x, int B, int HW, int C, float scale, float* out, use_stream_t stream);
+int use_op_dense_bwd(const float* g, const float* temb, const float* Wd, int B, int K, int Cout, float* dW, float* db, float* dtemb,
+                     use_stream_t stream);
 /* ---- wire formats either side of the path, host functions: no device, no handle ----
  * use_wav_read: RIFF/WAVE (PCM 8/16/24/32-bit, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE) -> interleaved float64 frames scaled like
  *   libsndfile's sf.read (integer PCM / 2^(bits-1)); *samples is malloc'ed, release it with use_free.

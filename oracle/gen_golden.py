@@ -12,6 +12,7 @@ source is copied: the fixtures hold data only.
 Fixtures
   fir.npz           upsample_2d / downsample_2d on [2,5,16,12]                      (G1)
   resblock_*.npz    ResnetBlockBigGANpp plain / widen / down / up / cat-input        (G1)
+  resblock_grads_*  gradients of the plain / widen block from the reference's backward()  (8f4)
   attn.npz          AttnBlockpp [2,32,8,5]                                          (G1)
   forward_large.npz NCSNppLarge.forward [2,2,512,64], t in {1.0,0.5} and {0.03,0.2}  (G2)
   sampler_*.npz     get_pc_sampler with an analytic score_fn, N=7: reverse_diffusion x {none, langevin, ald},
@@ -95,6 +96,23 @@ def gen_resblocks():
             y = blk(x, temb)
         np.savez(os.path.join(OUT, f"resblock_{name}.npz"), x=x.numpy(), temb=temb.numpy(), y=y.numpy(),
                  **{"w." + k: v for k, v in w.items()})
+
+
+def gen_resblock_grads():
+    """Gradients of ResnetBlockBigGANpp from the reference's own backward() (the backward half of train_step), for the
+    `plain` (residual) and `widen` (1x1 shortcut) blocks of gen_resblocks - same module, weights and inputs; loss = sum(y * gy)."""
+    act = torch.nn.SiLU()
+    for name, kw in {"plain": dict(in_ch=16, out_ch=16), "widen": dict(in_ch=16, out_ch=32)}.items():
+        blk = layerspp.ResnetBlockBigGANpp(act=act, temb_dim=24, dropout=0.0, fir=True, fir_kernel=[1, 3, 3, 1],
+                                          init_scale=0.0, skip_rescale=True, **kw).eval()
+        fill_module(blk, 7, name)
+        x = rnd(2, name + "x", (2, kw["in_ch"], 12, 10)).requires_grad_(True)
+        temb = rnd(2, name + "t", (2, 24)).requires_grad_(True)
+        y = blk(x, temb)
+        gy = rnd(4, name + "gy", tuple(y.shape))
+        (y * gy).sum().backward()
+        np.savez(os.path.join(OUT, f"resblock_grads_{name}.npz"), gy=gy.numpy(), dx=x.grad.numpy(), dtemb=temb.grad.numpy(),
+                 **{"d." + k: v.grad.numpy() for k, v in blk.named_parameters()})
 
 
 def gen_attn():
@@ -350,7 +368,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    small = {"fir": gen_fir, "resblocks": gen_resblocks, "attn": gen_attn, "samplers": gen_samplers, "samplers_em": gen_samplers_em,
+    small = {"fir": gen_fir, "resblocks": gen_resblocks, "resblock_grads": gen_resblock_grads, "attn": gen_attn, "samplers": gen_samplers, "samplers_em": gen_samplers_em,
              "refine": gen_refine, "forward_small": gen_forward_small, "both": gen_both,
              "train_loss": gen_train_loss}
     big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1,

@@ -1,0 +1,78 @@
+"""SURVEY 8f4, minimum slice: gradients of one ResnetBlockBigGANpp through the HIP backward operators (use_op_wgrad, use_op_gn_act_bwd,
+use_op_colsum, use_op_dense_bwd, and use_op_conv on flipped weights for the data gradients) against the gradients the REFERENCE's own
+backward() produced (tests/golden/resblock_grads_{plain,widen}.npz, oracle/gen_golden.py).  fp32 storage; bound 1e-4 of each tensor's max."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def _nhwc(x, cp):
+    B, Cc, H, W = x.shape
+    y = torch.zeros(B, H, W, cp)
+    y[..., :Cc] = x.permute(0, 2, 3, 1)
+    return y.cuda().contiguous()
+
+
+@pytest.mark.parametrize("name", ["plain", "widen"])
+def test_resblock_gradients_match_the_reference_backward(golden_dir, name):
+    from universal_speech_enhancement_amd import training_ops as T
+    f = np.load(os.path.join(golden_dir, f"resblock_{name}.npz"))
+    gr = np.load(os.path.join(golden_dir, f"resblock_grads_{name}.npz"))
+    Wt = {k[2:]: torch.from_numpy(f[k]) for k in f.files if k.startswith("w.")}
+    x, temb, gy = torch.from_numpy(f["x"]), torch.from_numpy(f["temb"]), torch.from_numpy(gr["gy"])
+    B, Cin, H, Wd = x.shape
+    Cout = Wt["Conv_0.weight"].shape[0]
+    cip, cop = _pad32(Cin), _pad32(Cout)
+
+    def padw(w, o, i):
+        z = torch.zeros(o, i, *w.shape[2:]); z[:w.shape[0], :w.shape[1]] = w
+        return z
+
+    def padv(v, n):
+        z = torch.zeros(n); z[:v.shape[0]] = v
+        return z
+
+    W = {"Conv_0.weight": padw(Wt["Conv_0.weight"], cop, cip).numpy(), "Conv_1.weight": padw(Wt["Conv_1.weight"], cop, cop).numpy()}
+    if "Conv_2.weight" in Wt:
+        W["Conv_2.weight"] = padw(Wt["Conv_2.weight"][:, :, 0, 0], cop, cip).numpy()
+    for k, n in (("GroupNorm_0.weight", cip), ("GroupNorm_0.bias", cip), ("GroupNorm_1.weight", cop), ("GroupNorm_1.bias", cop)):
+        W[k + ".dev"] = padv(Wt[k], n).cuda()
+    Wdense = torch.zeros(cop, 24); Wdense[:Cout] = Wt["Dense_0.weight"]
+    W["Dense_0.weight.dev"] = Wdense.cuda().contiguous()
+    g0 = cip // (Cin // min(Cin // 4, 32)); g1 = cop // (Cout // min(Cout // 4, 32))       # groups incl. the padding's all-zero groups
+    xd, gyd, tembd = _nhwc(x, cip), _nhwc(gy, cop), temb.cuda().contiguous()
+    # forward up to Conv_0's output (the activation the backward needs), with the library's forward operator
+    a0 = T.gn_act_fwd(xd, W["GroupNorm_0.weight.dev"], W["GroupNorm_0.bias.dev"], g0)
+    tv = torch.zeros(B, cop); tv[:, :Cout] = torch.nn.functional.linear(torch.nn.functional.silu(temb), Wt["Dense_0.weight"], Wt["Dense_0.bias"])
+    h1 = T.conv_fwd(a0, W["Conv_0.weight"], bias=padv(Wt["Conv_0.bias"], cop).numpy(), temb=tv.cuda().contiguous())
+    g = T.resblock_backward(xd, h1, tembd, gyd, W, g0, g1)
+    torch.cuda.synchronize()
+
+    def rel(got, want):
+        return float((got - want).abs().max() / want.abs().max())
+
+    checks = {"x": (g["x"].cpu()[..., :Cin].permute(0, 3, 1, 2), gr["dx"]), "temb": (g["temb"].cpu(), gr["dtemb"]),
+              "Conv_0.weight": (g["Conv_0.weight"].cpu()[:Cout, :Cin], gr["d.Conv_0.weight"]), "Conv_0.bias": (g["Conv_0.bias"].cpu()[:Cout], gr["d.Conv_0.bias"]),
+              "Conv_1.weight": (g["Conv_1.weight"].cpu()[:Cout, :Cout], gr["d.Conv_1.weight"]), "Conv_1.bias": (g["Conv_1.bias"].cpu()[:Cout], gr["d.Conv_1.bias"]),
+              "GroupNorm_0.weight": (g["GroupNorm_0.weight"].cpu()[:Cin], gr["d.GroupNorm_0.weight"]),
+              "GroupNorm_0.bias": (g["GroupNorm_0.bias"].cpu()[:Cin], gr["d.GroupNorm_0.bias"]),
+              "GroupNorm_1.weight": (g["GroupNorm_1.weight"].cpu()[:Cout], gr["d.GroupNorm_1.weight"]),
+              "GroupNorm_1.bias": (g["GroupNorm_1.bias"].cpu()[:Cout], gr["d.GroupNorm_1.bias"]),
+              "Dense_0.weight": (g["Dense_0.weight"].cpu()[:Cout], gr["d.Dense_0.weight"]), "Dense_0.bias": (g["Dense_0.bias"].cpu()[:Cout], gr["d.Dense_0.bias"])}
+    if "Conv_2.weight" in W:
+        checks["Conv_2.weight"] = (g["Conv_2.weight"].cpu()[:Cout, :Cin], gr["d.Conv_2.weight"][:, :, 0, 0])
+        checks["Conv_2.bias"] = (g["Conv_2.bias"].cpu()[:Cout], gr["d.Conv_2.bias"])
+    worst = 0.0
+    for k, (got, want) in checks.items():
+        e = rel(got, torch.from_numpy(np.asarray(want)))
+        print(f"[measured] resblock_{name} grad {k}: {e:.3g}")
+        worst = max(worst, e)
+        assert e < 1e-4, (name, k, e)

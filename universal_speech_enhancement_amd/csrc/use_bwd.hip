@@ -1,0 +1,256 @@
+// Backward kernels of one ResnetBlockBigGANpp (the gradient half of ScoreModel.train_step, reference
+// model_wrapper.py:147-208 driven by SGMSE_module.py:46-54) - the minimum slice: everything one res-block needs besides the data
+// gradient of its convolutions, which is the forward implicit-GEMM kernel itself run on the flipped, transposed weights.
+//
+//   wgrad_kernel          dW[co][ci][tap] = alpha * sum_{b,p} dY[b,p,co] X[b,p+tap,ci]     (and db[co] = alpha * sum dY)
+//   gn_stats_kernel       mean / rstd per (item, group) of an NHWC map                       (GroupNorm(eps) statistics)
+//   gn_act_bwd_reduce     s1[b][c] = sum_p du, s2[b][c] = sum_p du xhat,  du = dy * act'(gamma xhat + beta)
+//   gn_act_bwd_apply      dx = rstd (gamma du - m1 - xhat m2) [+ add_scale * add],  m1 / m2 = group means of gamma s1 / gamma s2
+//   gn_act_fwd            y = act(gamma xhat + beta)                                        (operand of the next wgrad; recomputed)
+//   gn_param_grads        dgamma[c] = sum_b s2, dbeta[c] = sum_b s1
+//   colsum_kernel         out[b][c] = sum_p x[b,p,c]                                          (Dense_0's upstream gradient)
+//   dense_bwd_kernel      Dense_0(act(temb)): dW, db, dtemb
+//
+// fp32 storage, NHWC ([B][H][W][C]); the contraction of wgrad runs on the matrix pipe in exact fp32 (v_mfma_f32_32x32x2_f32: K = pixels,
+// 2 per instruction, one float per lane and operand - both operands are read coalesced over channels straight from NHWC).
+#include "use_kernels.h"
+#include "use_device.h"
+
+namespace use {
+
+// ---- weight gradient ---------------------------------------------------------------------------------------------------------------
+// grid (co blocks of 32, ci blocks of 32, taps x pixel slices); 256 threads = 4 waves, each wave walks every 4th pixel pair of its slice;
+// the four partial 32x32 tiles are summed through LDS and added to dW with atomics (pixel slices > 1) or stored.
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                                    float* __restrict__ db, int B, int H, int W, int Cout, int Cin, int ntaps, int nslices,
+                                                    float alpha) {
+    __shared__ float red[4][32][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+    const int tap = blockIdx.z % ntaps, slice = blockIdx.z / ntaps;
+    const int dyy = ntaps == 9 ? tap / 3 - 1 : 0, dxx = ntaps == 9 ? tap % 3 - 1 : 0;
+    const long npix = (long)B * H * W;
+    const long per = (npix + nslices - 1) / nslices, p_lo = (long)slice * per, p_hi = p_lo + per < npix ? p_lo + per : npix;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    const bool co_ok = co0 + l31 < Cout, ci_ok = ci0 + l31 < Cin;
+    for (long p0 = p_lo + wave * 2; p0 < p_hi; p0 += 8) {
+        const long p = p0 + hh;                               // this lane's pixel of the pair (k index of the MFMA)
+        float a = 0.f, bv = 0.f;
+        if (p < p_hi) {
+            if (co_ok) a = dy[p * Cout + co0 + l31];
+            const int xw = (int)(p % W), yh = (int)((p / W) % H);
+            const int ys = yh + dyy, xs = xw + dxx;
+            if (ci_ok && ys >= 0 && ys < H && xs >= 0 && xs < W) bv = x[(p + (long)dyy * W + dxx) * Cin + ci0 + l31];
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);     // D[co][ci] += sum_k dY[k][co] X[k][ci]
+        bsum += a;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * hh][l31] = acc[r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+        const int m = e >> 5, n = e & 31;
+        const float v = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
+        if (co0 + m < Cout && ci0 + n < Cin) {
+            float* d = dw + ((size_t)(co0 + m) * Cin + ci0 + n) * ntaps + tap;
+            if (nslices > 1) atomicAdd(d, v * alpha); else *d = v * alpha;
+        }
+    }
+    if (db && blockIdx.y == 0 && tap == ntaps / 2) {        // bias gradient: column sums of dY (once per co block and slice)
+        bsum += __shfl_xor(bsum, 32);
+        __syncthreads();
+        if (lane < 32) red[wave][0][lane] = bsum;
+        __syncthreads();
+        if (threadIdx.x < 32 && co0 + threadIdx.x < Cout) {
+            const float v = (red[0][0][threadIdx.x] + red[1][0][threadIdx.x]) + (red[2][0][threadIdx.x] + red[3][0][threadIdx.x]);
+            if (nslices > 1) atomicAdd(db + co0 + threadIdx.x, v * alpha); else db[co0 + threadIdx.x] = v * alpha;
+        }
+    }
+}
+
+// ---- GroupNorm statistics: one block per (item, group) -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int HW, int C, int G, float eps, float* __restrict__ mean,
+                                                       float* __restrict__ rstd) {
+    const int b = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G;
+    double s = 0.0, q = 0.0;
+    for (long i = threadIdx.x; i < (long)HW * cpg; i += 256) {
+        const float v = x[((size_t)b * HW + i / cpg) * C + g * cpg + i % cpg];
+        s += v; q += (double)v * v;
+    }
+    __shared__ double rs[4], rq[4];
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rq[threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double n = (double)HW * cpg, m = (rs[0] + rs[1] + rs[2] + rs[3]) / n;
+        double var = (rq[0] + rq[1] + rq[2] + rq[3]) / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[blockIdx.x] = (float)m; rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+template <bool ACT>
+__device__ __forceinline__ float act_grad(float u) {
+    if (!ACT) return 1.f;
+    const float sg = 1.0f / (1.0f + expf(-u));
+    return sg * (1.0f + u * (1.0f - sg));                    // d/du [u sigmoid(u)]
+}
+
+// s1[b][c] = sum_p du, s2[b][c] = sum_p du xhat; grid (channel blocks of 64, B), 256 threads = 4 pixel phases x 64 channels
+template <bool ACT>
+__global__ __launch_bounds__(256) void gn_act_bwd_reduce(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int HW, int C, int G, float* __restrict__ s1,
+                                                         float* __restrict__ s2) {
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C) {
+        const int g = c / (C / G);
+        const float mu = mean[b * G + g], rs = rstd[b * G + g], gm = gamma[c], bt = beta[c];
+        for (int p = ph; p < HW; p += 4) {
+            const size_t i = ((size_t)b * HW + p) * C + c;
+            const float xh = (x[i] - mu) * rs;
+            const float du = dy[i] * act_grad<ACT>(fmaf(gm, xh, bt));
+            a1 += du; a2 += (double)du * xh;
+        }
+    }
+    __shared__ double r1[4][64], r2[4][64];
+    r1[ph][threadIdx.x & 63] = a1; r2[ph][threadIdx.x & 63] = a2;
+    __syncthreads();
+    if (ph == 0 && c < C) {
+        const int l = threadIdx.x;
+        s1[(size_t)b * C + c] = (float)((r1[0][l] + r1[1][l]) + (r1[2][l] + r1[3][l]));
+        s2[(size_t)b * C + c] = (float)((r2[0][l] + r2[1][l]) + (r2[2][l] + r2[3][l]));
+    }
+}
+
+// dx = rstd (gamma du - m1 - xhat m2) + add_scale * add; m1, m2 = means over the group (channels x pixels) of gamma du, gamma du xhat
+template <bool ACT>
+__global__ __launch_bounds__(256) void gn_act_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ s1, const float* __restrict__ s2,
+                                                        const float* __restrict__ add, float add_scale, int HW, int C, int G,
+                                                        float* __restrict__ dx, long n) {
+    const int cpg = C / G;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C), b = (int)(i / ((long)HW * C)), g = c / cpg;
+        double m1 = 0.0, m2 = 0.0;
+        for (int k = 0; k < cpg; ++k) {
+            const int cc = g * cpg + k;
+            m1 += (double)gamma[cc] * s1[(size_t)b * C + cc]; m2 += (double)gamma[cc] * s2[(size_t)b * C + cc];
+        }
+        const double inv = 1.0 / ((double)HW * cpg);
+        const float mu = mean[b * G + g], rs = rstd[b * G + g];
+        const float xh = (x[i] - mu) * rs;
+        const float du = dy[i] * act_grad<ACT>(fmaf(gamma[c], xh, beta[c]));
+        float v = rs * (gamma[c] * du - (float)(m1 * inv) - xh * (float)(m2 * inv));
+        if (add) v += add_scale * add[i];
+        dx[i] = v;
+    }
+}
+
+// y = act(gamma xhat + beta): the activation a convolution's weight gradient is taken against (recomputed, not stored by the forward)
+template <bool ACT>
+__global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C, int G,
+                                                         float* __restrict__ y, long n) {
+    const int cpg = C / G;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C), b = (int)(i / ((long)HW * C)), g = c / cpg;
+        const float u = fmaf(gamma[c], (x[i] - mean[b * G + g]) * rstd[b * G + g], beta[c]);
+        y[i] = ACT ? u / (1.0f + expf(-u)) : u;
+    }
+}
+
+__global__ void gn_param_grads_kernel(const float* __restrict__ s1, const float* __restrict__ s2, int B, int C, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, bsum = 0.0;
+    for (int b = 0; b < B; ++b) { a += s2[(size_t)b * C + c]; bsum += s1[(size_t)b * C + c]; }
+    dgamma[c] = (float)a; dbeta[c] = (float)bsum;
+}
+
+// out[b][c] = scale * sum_p x[b,p,c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int HW, int C, float scale, float* __restrict__ out) {
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    double a = 0.0;
+    if (c < C) for (int p = ph; p < HW; p += 4) a += x[((size_t)b * HW + p) * C + c];
+    __shared__ double r[4][64];
+    r[ph][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (ph == 0 && c < C) { const int l = threadIdx.x; out[(size_t)b * C + c] = (float)(((r[0][l] + r[1][l]) + (r[2][l] + r[3][l])) * scale); }
+}
+
+// Dense_0(act(temb)) [B][K] -> [B][Cout]: g = upstream gradient [B][Cout]; dW[co][k] = sum_b g act(temb), db[co] = sum_b g,
+// dtemb[b][k] = act'(temb[b][k]) sum_co g[b][co] W[co][k]     (one block; these are [2..64] x [512] x [<=512] problems)
+__global__ __launch_bounds__(256) void dense_bwd_kernel(const float* __restrict__ g, const float* __restrict__ temb, const float* __restrict__ Wd,
+                                                        int B, int K, int Cout, float* __restrict__ dW, float* __restrict__ db,
+                                                        float* __restrict__ dtemb) {
+    for (int e = threadIdx.x; e < Cout * K; e += 256) {
+        const int co = e / K, k = e % K;
+        double a = 0.0;
+        for (int b = 0; b < B; ++b) { const float t = temb[b * K + k]; a += (double)g[b * Cout + co] * (t / (1.0f + expf(-t))); }
+        dW[e] = (float)a;
+    }
+    for (int co = threadIdx.x; co < Cout; co += 256) {
+        double a = 0.0;
+        for (int b = 0; b < B; ++b) a += g[b * Cout + co];
+        db[co] = (float)a;
+    }
+    for (int e = threadIdx.x; e < B * K; e += 256) {
+        const int b = e / K, k = e % K;
+        double a = 0.0;
+        for (int co = 0; co < Cout; ++co) a += (double)g[b * Cout + co] * Wd[co * K + k];
+        dtemb[e] = (float)a * act_grad<true>(temb[e]);
+    }
+}
+
+// ---- launch wrappers ------------------------------------------------------------------------------------------------------------
+void launch_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
+                  hipStream_t s) {
+    const long npix = (long)B * H * W;
+    int nslices = (int)std::min<long>(64, std::max<long>(1, npix / 4096));     // pixel slices (atomic accumulation when > 1)
+    if (nslices > 1) {
+        (void)hipMemsetAsync(dw, 0, (size_t)Cout * Cin * ntaps * 4, s);
+        if (db) (void)hipMemsetAsync(db, 0, (size_t)Cout * 4, s);
+    }
+    hipLaunchKernelGGL(wgrad_kernel, dim3((Cout + 31) / 32, (Cin + 31) / 32, ntaps * nslices), dim3(256), 0, s, dy, x, dw, db, B, H, W, Cout, Cin,
+                       ntaps, nslices, alpha);
+}
+void launch_gn_stats(const float* x, int B, int HW, int C, int G, float eps, float* mean, float* rstd, hipStream_t s) {
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * G), dim3(256), 0, s, x, HW, C, G, eps, mean, rstd);
+}
+void launch_gn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                       const float* add, float add_scale, int B, int HW, int C, int G, float* s1, float* s2, float* dx, float* dgamma,
+                       float* dbeta, hipStream_t s) {
+    const dim3 gr((C + 63) / 64, B);
+    const long n = (long)B * HW * C;
+    const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 4096);
+    if (act) {
+        hipLaunchKernelGGL(gn_act_bwd_reduce<true>, gr, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, s1, s2);
+        hipLaunchKernelGGL(gn_act_bwd_apply<true>, dim3(blocks), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, s1, s2, add, add_scale, HW, C, G, dx, n);
+    } else {
+        hipLaunchKernelGGL(gn_act_bwd_reduce<false>, gr, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, s1, s2);
+        hipLaunchKernelGGL(gn_act_bwd_apply<false>, dim3(blocks), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, s1, s2, add, add_scale, HW, C, G, dx, n);
+    }
+    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 127) / 128), dim3(128), 0, s, s1, s2, B, C, dgamma, dbeta);
+}
+void launch_gn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int B, int HW, int C,
+                       int G, float* y, hipStream_t s) {
+    const long n = (long)B * HW * C;
+    const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 4096);
+    if (act) hipLaunchKernelGGL(gn_act_fwd_kernel<true>, dim3(blocks), dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y, n);
+    else     hipLaunchKernelGGL(gn_act_fwd_kernel<false>, dim3(blocks), dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y, n);
+}
+void launch_colsum(const float* x, int B, int HW, int C, float scale, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, x, HW, C, scale, out);
+}
+void launch_dense_bwd(const float* g, const float* temb, const float* Wd, int B, int K, int Cout, float* dW, float* db, float* dtemb, hipStream_t s) {
+    hipLaunchKernelGGL(dense_bwd_kernel, dim3(1), dim3(256), 0, s, g, temb, Wd, B, K, Cout, dW, db, dtemb);
+}
+
+}  // namespace use

@@ -1745,6 +1745,46 @@ int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C
     return USE_OK;
 }
 
+// ---- backward operators (fp32 NHWC device tensors; SURVEY 8f4 minimum slice: one res-block) ----
+int use_op_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
+                 use_stream_t stream) {
+    if (!dy || !x || !dw || B < 1 || H < 1 || W < 1 || Cout < 1 || Cin < 1 || (ntaps != 1 && ntaps != 9)) return fail(USE_E_INVALID, "use_op_wgrad: bad argument");
+    launch_wgrad(dy, x, dw, db, B, H, W, Cout, Cin, ntaps, alpha, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+int use_op_gn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, int groups, float eps, int act, const float* add,
+                      float add_scale, int B, int HW, int C, float* work, float* dx, float* dgamma, float* dbeta, use_stream_t stream) {
+    if (!x || !dy || !gamma || !beta || !work || !dx || !dgamma || !dbeta || groups < 1 || C % groups) return fail(USE_E_INVALID, "use_op_gn_act_bwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    float* mean = work; float* rstd = work + (size_t)B * groups; float* s1 = rstd + (size_t)B * groups; float* s2 = s1 + (size_t)B * C;
+    launch_gn_stats(x, B, HW, C, groups, eps, mean, rstd, s);
+    launch_gn_act_bwd(x, dy, mean, rstd, gamma, beta, act, add, add_scale, B, HW, C, groups, s1, s2, dx, dgamma, dbeta, s);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+int use_op_gn_act_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, int act, int B, int HW, int C, float* work,
+                      float* y, use_stream_t stream) {
+    if (!x || !gamma || !beta || !work || !y || groups < 1 || C % groups) return fail(USE_E_INVALID, "use_op_gn_act_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    launch_gn_stats(x, B, HW, C, groups, eps, work, work + (size_t)B * groups, s);
+    launch_gn_act_fwd(x, work, work + (size_t)B * groups, gamma, beta, act, B, HW, C, groups, y, s);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+int use_op_colsum(const float* x, int B, int HW, int C, float scale, float* out, use_stream_t stream) {
+    if (!x || !out) return fail(USE_E_INVALID, "use_op_colsum: null tensor");
+    launch_colsum(x, B, HW, C, scale, out, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+int use_op_dense_bwd(const float* g, const float* temb, const float* Wd, int B, int K, int Cout, float* dW, float* db, float* dtemb, use_stream_t stream) {
+    if (!g || !temb || !Wd || !dW || !db || !dtemb) return fail(USE_E_INVALID, "use_op_dense_bwd: null tensor");
+    launch_dense_bwd(g, temb, Wd, B, K, Cout, dW, db, dtemb, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+
 int use_debug_tensor(use_handle* h, const char* name, void** dev_ptr, int* dims4, int* dtype) {
     if (!h || !name) return fail(USE_E_INVALID, "null argument");
     auto it = h->debug.find(name);

@@ -159,6 +159,19 @@ void launch_transpose_nc(const void* in, void* out, int dtype, int B, int N, int
 void launch_score_out(const float* pyr, int pc, const float* t, int t_stride, const float* w, const float* bias,
                       float2* score, int B, long pix_per_b, float sign, hipStream_t s);     // pc = 4 or 8 pyramid channels
 
+// ---- backward kernels of one res-block (use_bwd.hip; fp32 storage, NHWC): the gradient half of train_step, minimum slice ----
+void launch_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
+                  hipStream_t s);                            // dW [Cout][Cin][ntaps] (reference layout), db [Cout] or null
+void launch_gn_stats(const float* x, int B, int HW, int C, int G, float eps, float* mean, float* rstd, hipStream_t s);
+// dx = d/dx of act(GroupNorm(x)) against dy, + add_scale * add (or add == null); s1 / s2: [B][C] scratch; dgamma / dbeta [C]
+void launch_gn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                       const float* add, float add_scale, int B, int HW, int C, int G, float* s1, float* s2, float* dx, float* dgamma,
+                       float* dbeta, hipStream_t s);
+void launch_gn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int B, int HW, int C,
+                       int G, float* y, hipStream_t s);
+void launch_colsum(const float* x, int B, int HW, int C, float scale, float* out, hipStream_t s);       // out[b][c] = scale * sum_p x[b,p,c]
+void launch_dense_bwd(const float* g, const float* temb, const float* Wd, int B, int K, int Cout, float* dW, float* db, float* dtemb, hipStream_t s);
+
 // ---- SDE updates (complex64 as float2, fp32 arithmetic) ----
 struct RngRef { const unsigned long long* state; unsigned draw; };  // state[0]=seed, state[1]=draw base
 // z source: noise != null -> read noise[i]; else Philox(seed, draw)

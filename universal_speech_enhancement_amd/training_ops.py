@@ -1,0 +1,137 @@
+"""Backward pass of one ``ResnetBlockBigGANpp`` on the HIP operators (minimum slice): the gradient half of the
+reference's ``ScoreModel.train_step`` (model_wrapper.py:147-208, driven by ``SGMSEModule.training_step``, SGMSE_module.py:46-54)
+needs, per res-block, the data and weight gradients of two 3x3 convolutions and the 1x1 shortcut, the backward of two
+GroupNorm + SiLU pairs and of Dense_0(SiLU(temb)).  fp32 storage, NHWC device tensors, plain res-block (no FIR resampling).
+
+* data gradient of a convolution = the forward implicit-GEMM kernel (``use_op_conv``) on the flipped, transposed weights;
+* weight gradient = ``use_op_wgrad`` (pixels as the K of an exact-fp32 MFMA contraction);
+* GroupNorm + SiLU backward = ``use_op_gn_act_bwd``; Dense_0 = ``use_op_colsum`` + ``use_op_dense_bwd``.
+
+The forward activations the backward needs (block input, Conv_0 output) are recomputed / taken from the forward operators by the caller;
+this module only moves pointers.  Training itself (optimiser, whole-network backward) remains outside the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import UseConvOp, check
+
+SQRT1_2 = 0.70710678118654752440
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def conv_fwd(x, w, bias=None, coef=None, act=0, temb=None, res=None, x0=None, w2=None, scale=1.0, ntaps=9, stats=None):
+    """The library's fused convolution on fp32 NHWC tensors whose channel counts are multiples of 32 (``use_op_conv``)."""
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
+    op = UseConvOp()
+    op.B, op.H, op.W, op.C0, op.C1, op.Cout, op.ntaps, op.act, op.dtype, op.out_dtype, op.variant = B, H, W, Cin, 0, Cout, ntaps, act, 0, 0, 0
+    op.src0 = x.data_ptr()
+    keep = [np.ascontiguousarray(w, dtype=np.float32)]
+    op.w = keep[0].ctypes.data
+    if bias is not None:
+        keep.append(np.ascontiguousarray(bias, dtype=np.float32)); op.bias = keep[-1].ctypes.data
+    if x0 is not None:
+        op.XC0 = x0.shape[3]; op.x0 = x0.data_ptr()
+        keep.append(np.ascontiguousarray(w2, dtype=np.float32)); op.w2 = keep[-1].ctypes.data
+    op.coef = coef.data_ptr() if coef is not None else None
+    op.temb = temb.data_ptr() if temb is not None else None
+    op.res = res.data_ptr() if res is not None else None
+    op.out_scale = scale; op.out = out.data_ptr(); op.stats = stats.data_ptr() if stats is not None else None
+    check(_lib.lib().use_op_conv(C.byref(op), _stream()), "use_op_conv")
+    return out
+
+
+def conv_dgrad(dy, w, scale=1.0):
+    """dX of y = conv3x3(x, w) (or conv1x1 for a 2-D w): the same kernel on w'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]."""
+    if w.ndim == 4:
+        wt = np.ascontiguousarray(np.flip(np.asarray(w), (2, 3)).transpose(1, 0, 2, 3))
+        return conv_fwd(dy, wt, scale=scale)
+    return conv_fwd(dy, np.ascontiguousarray(np.asarray(w).T), scale=scale, ntaps=1)
+
+
+def conv_wgrad(dy, x, ntaps=9, alpha=1.0, with_bias=True):
+    B, H, W, Cout = dy.shape
+    Cin = x.shape[3]
+    dw = torch.empty(Cout, Cin, *((3, 3) if ntaps == 9 else ()), dtype=torch.float32, device=dy.device)
+    db = torch.empty(Cout, dtype=torch.float32, device=dy.device) if with_bias else None
+    check(_lib.lib().use_op_wgrad(_p(dy), _p(x), _p(dw), _p(db), B, H, W, Cout, Cin, ntaps, alpha, _stream()), "use_op_wgrad")
+    return dw, db
+
+
+def gn_act_bwd(x, dy, gamma, beta, groups, act=1, add=None, add_scale=1.0, eps=1e-6):
+    B, H, W, Cc = x.shape
+    work = torch.empty(2 * B * (groups + Cc), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dg, dbt = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
+    check(_lib.lib().use_op_gn_act_bwd(_p(x), _p(dy), _p(gamma), _p(beta), groups, eps, act, _p(add), add_scale, B, H * W, Cc, _p(work), _p(dx),
+                                        _p(dg), _p(dbt), _stream()), "use_op_gn_act_bwd")
+    return dx, dg, dbt
+
+
+def gn_act_fwd(x, gamma, beta, groups, act=1, eps=1e-6):
+    """act(GroupNorm(x)) - the operand of the following convolution's weight gradient, recomputed from the stored pre-activation."""
+    B, H, W, Cc = x.shape
+    work = torch.empty(2 * B * groups, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    check(_lib.lib().use_op_gn_act_fwd(_p(x), _p(gamma), _p(beta), groups, eps, act, B, H * W, Cc, _p(work), _p(y), _stream()), "use_op_gn_act_fwd")
+    return y
+
+
+def dense_bwd(g, temb, Wd):
+    B, Cout = g.shape
+    K = temb.shape[1]
+    dW, db, dt = torch.empty(Cout, K, device=g.device), torch.empty(Cout, device=g.device), torch.empty(B, K, device=g.device)
+    check(_lib.lib().use_op_dense_bwd(_p(g), _p(temb), _p(Wd), B, K, Cout, _p(dW), _p(db), _p(dt), _stream()), "use_op_dense_bwd")
+    return dW, db, dt
+
+
+def colsum(x, scale=1.0):
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, Cc, device=x.device)
+    check(_lib.lib().use_op_colsum(_p(x), B, H * W, Cc, scale, _p(out), _stream()), "use_op_colsum")
+    return out
+
+
+def resblock_backward(x, h1, temb, gy, W, groups0, groups1):
+    """Gradients of y = (shortcut(x) + Conv_1(SiLU(GN_1(h1)))) / sqrt(2), h1 = Conv_0(SiLU(GN_0(x))) + Dense_0(SiLU(temb)), given gy = dL/dy.
+    x [B,H,W,Cin], h1 [B,H,W,Cout] (the forward's Conv_0 output), gy [B,H,W,Cout]: fp32 NHWC on the GPU, channels multiples of 32
+    (zero-padded; `groups*` count the padding's all-zero groups as well).  W: the block's parameters (torch CPU tensors, padded alike;
+    GroupNorm / Dense parameters also as CUDA tensors under the same keys + '.dev').  Returns dict of gradients."""
+    g = {}
+    # Conv_1 (and the shortcut) see gy / sqrt(2)
+    h2_in = h1                                                            # GN_1 + SiLU are recomputed inside the kernels from h1
+    a1 = gn_act_fwd(h1, W["GroupNorm_1.weight.dev"], W["GroupNorm_1.bias.dev"], groups1)     # operand of Conv_1's weight gradient (recomputed)
+    g["Conv_1.weight"], g["Conv_1.bias"] = conv_wgrad(gy, a1, alpha=SQRT1_2)
+    da1 = conv_dgrad(gy, W["Conv_1.weight"], scale=SQRT1_2)
+    dh1, g["GroupNorm_1.weight"], g["GroupNorm_1.bias"] = gn_act_bwd(h2_in, da1, W["GroupNorm_1.weight.dev"], W["GroupNorm_1.bias.dev"], groups1)
+    # Dense_0(SiLU(temb)) is broadcast over the pixels of h1
+    g["Dense_0.weight"], g["Dense_0.bias"], g["temb"] = dense_bwd(colsum(dh1), temb, W["Dense_0.weight.dev"])
+    a0 = gn_act_fwd(x, W["GroupNorm_0.weight.dev"], W["GroupNorm_0.bias.dev"], groups0)
+    g["Conv_0.weight"], g["Conv_0.bias"] = conv_wgrad(dh1, a0)
+    da0 = conv_dgrad(dh1, W["Conv_0.weight"])
+    if "Conv_2.weight" in W:                                              # 1x1 shortcut on the raw input
+        g["Conv_2.weight"], g["Conv_2.bias"] = conv_wgrad(gy, x, ntaps=1, alpha=SQRT1_2)
+        dsc = conv_dgrad(gy, W["Conv_2.weight"], scale=SQRT1_2)
+        g["x"], g["GroupNorm_0.weight"], g["GroupNorm_0.bias"] = gn_act_bwd(x, da0, W["GroupNorm_0.weight.dev"], W["GroupNorm_0.bias.dev"], groups0,
+                                                                           add=dsc, add_scale=1.0)
+    else:                                                                 # identity shortcut
+        g["x"], g["GroupNorm_0.weight"], g["GroupNorm_0.bias"] = gn_act_bwd(x, da0, W["GroupNorm_0.weight.dev"], W["GroupNorm_0.bias.dev"], groups0,
+                                                                           add=gy, add_scale=SQRT1_2)
+    return g
