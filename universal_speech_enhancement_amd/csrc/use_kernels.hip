@@ -433,6 +433,16 @@ __global__ __launch_bounds__(256) void pyr_conv_kernel(ConvArgs p) {
 // issues the halo loads of tile t+1 (registers) BEFORE it transforms and multiplies tile t; the weights of all taps (<= 2 blocks of
 // 128 input channels) and the GroupNorm affine of its channels are fetched once per workgroup.  Same arithmetic, same order.
 constexpr int PYRP_SMEM = PYR_HALO + 2 * PYR_WB + BM * 4 * 4;
+// 16x16x32 MFMA for the head: the 32x32x16 form computes 32 output columns of which 4 exist and chains all 36 MFMAs of a (tile, block)
+// unit through ONE accumulator (the matrix pipe's dependent-issue latency, not its rate, set the unit's duration); the 16x16x32 form has
+// a quarter of the passes per instruction and gives each wave two independent accumulators (its two 16-pixel rows).
+template <typename T> struct Mfma16;
+template <> struct Mfma16<__bf16> {
+    DEVI static f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16<_Float16> {
+    DEVI static f32x4 mma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
 template <typename T16>
 __global__ __launch_bounds__(256) void pyr_conv_pipe_kernel(ConvArgs p, int tiles_per_wg) {
     typedef Mfma<T16> MF;
@@ -447,8 +457,10 @@ __global__ __launch_bounds__(256) void pyr_conv_pipe_kernel(ConvArgs p, int tile
     const T16* src = (const T16*)p.src0;
     const int part = tid % PYR_PP;
     const int m = lane & 31;
-    const int a_base = (wave * 2 + (m >> 4)) * PYR_HPITCH + (m & 15) * PYR_ROWB + (lane >> 5) * 16;
-    const int b_base = (lane & 3) * PYR_ROWB + (lane >> 5) * 16;
+    // 16x16x32 fragments: lane -> (pixel column | output channel) lane & 15, 8-channel k group lane >> 4; row i of the wave: + i * PYR_HPITCH
+    const int a_base = (wave * 2) * PYR_HPITCH + (lane & 15) * PYR_ROWB + (lane >> 4) * 16;
+    const int b_base = (lane & 3) * PYR_ROWB + (lane >> 4) * 16;
+    (void)m;
     constexpr int NP = ((TILE_H + 2) * (TILE_W + 2) * PYR_PP + 255) / 256;
     // weights of every block, once
     for (int i = tid; i < nblk * 9 * 4 * PYR_PP; i += 256) {
@@ -494,12 +506,12 @@ __global__ __launch_bounds__(256) void pyr_conv_pipe_kernel(ConvArgs p, int tile
         }
     };
     if (nunits > 0) prefetch(0);
-    f32x16 acc;
+    f32x4 acc0, acc1;                                        // the wave's two 16-pixel rows
     for (int u = 0; u < nunits; ++u) {
         const int blk = u % nblk;
         if (blk == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
         }
         uint4 rawC[NP]; int dstC[NP];
 #pragma unroll
@@ -527,16 +539,21 @@ __global__ __launch_bounds__(256) void pyr_conv_pipe_kernel(ConvArgs p, int tile
             const char* ha = s_halo + a_base + (tap / 3) * PYR_HPITCH + (tap % 3) * PYR_ROWB;
             const char* wb = s_w + blk * PYR_WB + b_base + tap * 4 * PYR_ROWB;
 #pragma unroll
-            for (int kk = 0; kk < PYR_CB / 16; ++kk) acc = MF::mma(MF::ld(ha + kk * 32), MF::ld(wb + kk * 32), acc);
+            for (int kk = 0; kk < PYR_CB / 32; ++kk) {
+                const auto wf = MF::ld(wb + kk * 64);
+                acc0 = Mfma16<T16>::mma(MF::ld(ha + kk * 64), wf, acc0);
+                acc1 = Mfma16<T16>::mma(MF::ld(ha + PYR_HPITCH + kk * 64), wf, acc1);
+            }
         }
         if (blk == nblk - 1) {                                // tile complete: [128 px][4] through LDS, one pixel per thread
             const int tile = t_begin + u / nblk;
             const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
-            if ((lane & 31) < 4) {
+            if ((lane & 15) < 4) {                           // D of 16x16x32: column lane & 15 (output channel), rows 4 (lane >> 4) + r
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    s_out[(wave * 32 + row) * 4 + (lane & 31)] = acc[r];
+                for (int r = 0; r < 4; ++r) {
+                    const int col = 4 * (lane >> 4) + r;
+                    s_out[(wave * 32 + col) * 4 + (lane & 15)] = acc0[r];
+                    s_out[(wave * 32 + 16 + col) * 4 + (lane & 15)] = acc1[r];
                 }
             }
             __syncthreads();                                  // also: every wave is done with the halo
