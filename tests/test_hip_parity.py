@@ -930,3 +930,27 @@ def test_fused_attention_block_matches_the_oracle_block(golden_dir, engines, sd_
         want = no.attn_block(taps[1][0], sd, prefix)
     _check(_relmax(taps[1][1], want), tol, "fused attention block vs oracle block", prec)
     _check(_relmax(taps[0][1], want), tol, "unfused attention block vs oracle block", prec)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("Tp", [64, 192, 704])
+def test_fused_attention_block_at_other_token_counts(engines, prec, Tp):
+    """attn_fused_kernel with 8 / 24 / 88 tokens (one, one and three 32-token tiles, the last one partly filled): same block output as
+    the unfused path (three NIN launches, VALU attention core, NIN_3) up to the rounding of the probabilities (bound: 2x the T' = 64
+    golden-shape measurement of the block against the oracle, 4.9e-3 / 4.3e-4)."""
+    from universal_speech_enhancement_amd.hip_engine import set_option
+    eng = engines[prec]
+    x = torch.from_numpy(tnoise.complex_normal(31, f"xa{Tp}", (2, 1, 512, Tp))).cuda() * 0.5
+    y = torch.from_numpy(tnoise.complex_normal(32, f"ya{Tp}", (2, 1, 512, Tp))).cuda() * 0.5
+    t = torch.tensor([0.7, 0.1]).cuda()
+    taps = {}
+    for fused in (1, 0):
+        set_option("attn_fused", fused)
+        try:
+            eng.plan(2, Tp)
+            eng.score(x, y, t)
+            taps[fused] = eng.debug_tensor("post_attn").cpu()
+        finally:
+            set_option("attn_fused", 1)
+    assert torch.isfinite(taps[1]).all()
+    _check(_relmax(taps[1], taps[0]), 1.0e-2 if prec == "bf16" else 9e-4, "fused vs unfused attention block", prec, Tp)

@@ -1160,8 +1160,12 @@ int use_plan(use_handle* h, int B, int Tpad) {
     char* base = old_base;
     if (!base || total > h->arena_alloc) {
         if (base) { HIPCHK(hipFree(base)); base = nullptr; h->arena_alloc = 0; }
-        if (hipMalloc((void**)&base, total) != hipSuccess)
-            return fail(USE_E_NOMEM, "cannot allocate %.1f MB of activation workspace", total / 1e6);
+        if (hipMalloc((void**)&base, total) != hipSuccess) {
+            (void)hipGetLastError();
+            plan_cache_clear(h);                              // parked plans hold their workspaces: give them up and try once more
+            if (hipMalloc((void**)&base, total) != hipSuccess)
+                return fail(USE_E_NOMEM, "cannot allocate %.1f MB of activation workspace", total / 1e6);
+        }
         h->arena_alloc = total;
     }
     h->arena.base = base; h->arena.cap = total;               // owns the allocation (use_workspace_bytes reports cap)
@@ -1189,7 +1193,11 @@ int use_plan(use_handle* h, int B, int Tpad) {
     h->persist_bytes = off;
     if (!h->persist || off > h->persist_alloc) {
         if (h->persist) { HIPCHK(hipFree(h->persist)); h->persist = nullptr; h->persist_alloc = 0; }
-        if (hipMalloc((void**)&h->persist, off) != hipSuccess) return fail(USE_E_NOMEM, "cannot allocate %.1f MB of state", off / 1e6);
+        if (hipMalloc((void**)&h->persist, off) != hipSuccess) {
+            (void)hipGetLastError();
+            plan_cache_clear(h);
+            if (hipMalloc((void**)&h->persist, off) != hipSuccess) return fail(USE_E_NOMEM, "cannot allocate %.1f MB of state", off / 1e6);
+        }
         h->persist_alloc = off;
     }
     h->x4 = (float*)(h->persist + o_x4); h->Y = (float2*)(h->persist + o_Y); h->X = (float2*)(h->persist + o_X);
