@@ -100,9 +100,10 @@ def gen_resblocks():
 
 def gen_resblock_grads():
     """Gradients of ResnetBlockBigGANpp from the reference's own backward() (the backward half of train_step), for the
-    `plain` (residual) and `widen` (1x1 shortcut) blocks of gen_resblocks - same module, weights and inputs; loss = sum(y * gy)."""
+    `plain` (residual), `widen` (1x1 shortcut), `down` and `up` (FIR-resampled) blocks of gen_resblocks - same module, weights and inputs; loss = sum(y * gy)."""
     act = torch.nn.SiLU()
-    for name, kw in {"plain": dict(in_ch=16, out_ch=16), "widen": dict(in_ch=16, out_ch=32)}.items():
+    for name, kw in {"plain": dict(in_ch=16, out_ch=16), "widen": dict(in_ch=16, out_ch=32),
+                     "down": dict(in_ch=16, out_ch=16, down=True), "up": dict(in_ch=16, out_ch=16, up=True)}.items():
         blk = layerspp.ResnetBlockBigGANpp(act=act, temb_dim=24, dropout=0.0, fir=True, fir_kernel=[1, 3, 3, 1],
                                           init_scale=0.0, skip_rescale=True, **kw).eval()
         fill_module(blk, 7, name)

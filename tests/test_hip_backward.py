@@ -1,6 +1,6 @@
 """SURVEY 8f4, minimum slice: gradients of one ResnetBlockBigGANpp through the HIP backward operators (use_op_wgrad, use_op_gn_act_bwd,
 use_op_colsum, use_op_dense_bwd, and use_op_conv on flipped weights for the data gradients) against the gradients the REFERENCE's own
-backward() produced (tests/golden/resblock_grads_{plain,widen}.npz, oracle/gen_golden.py).  fp32 storage; bound 1e-4 of each tensor's max."""
+backward() produced (tests/golden/resblock_grads_{plain,widen,down,up}.npz, oracle/gen_golden.py).  fp32 storage; bound 1e-4 of each tensor's max."""
 import os
 
 import numpy as np
@@ -21,7 +21,7 @@ def _nhwc(x, cp):
     return y.cuda().contiguous()
 
 
-@pytest.mark.parametrize("name", ["plain", "widen"])
+@pytest.mark.parametrize("name", ["plain", "widen", "down", "up"])
 def test_resblock_gradients_match_the_reference_backward(golden_dir, name):
     from universal_speech_enhancement_amd import training_ops as T
     f = np.load(os.path.join(golden_dir, f"resblock_{name}.npz"))
@@ -52,8 +52,11 @@ def test_resblock_gradients_match_the_reference_backward(golden_dir, name):
     # forward up to Conv_0's output (the activation the backward needs), with the library's forward operator
     a0 = T.gn_act_fwd(xd, W["GroupNorm_0.weight.dev"], W["GroupNorm_0.bias.dev"], g0)
     tv = torch.zeros(B, cop); tv[:, :Cout] = torch.nn.functional.linear(torch.nn.functional.silu(temb), Wt["Dense_0.weight"], Wt["Dense_0.bias"])
+    up, down = name == "up", name == "down"
+    if up or down:
+        a0 = T.fir(a0, up=up)
     h1 = T.conv_fwd(a0, W["Conv_0.weight"], bias=padv(Wt["Conv_0.bias"], cop).numpy(), temb=tv.cuda().contiguous())
-    g = T.resblock_backward(xd, h1, tembd, gyd, W, g0, g1)
+    g = T.resblock_backward(xd, h1, tembd, gyd, W, g0, g1, up=up, down=down)
     torch.cuda.synchronize()
 
     def rel(got, want):

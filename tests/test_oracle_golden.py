@@ -176,7 +176,7 @@ def test_small_variants_match_reference(golden_dir, name, arch):
     assert err < 2e-5, err
 
 
-@pytest.mark.parametrize("name", ["plain", "widen"])
+@pytest.mark.parametrize("name", ["plain", "widen", "down", "up"])
 def test_oracle_resblock_gradients_match_reference_backward(golden_dir, name):
     """autograd through the oracle's functional res-block reproduces the gradients of the reference's own backward()
     (resblock_grads_*.npz) - the pin of the gradient goldens the HIP backward operators are tested against."""
@@ -184,7 +184,7 @@ def test_oracle_resblock_gradients_match_reference_backward(golden_dir, name):
     gr = np.load(os.path.join(golden_dir, f"resblock_grads_{name}.npz"))
     sd = {"blk." + k[2:]: torch.from_numpy(f[k]).requires_grad_(True) for k in f.files if k.startswith("w.")}
     x = torch.from_numpy(f["x"]).requires_grad_(True); temb = torch.from_numpy(f["temb"]).requires_grad_(True)
-    y = no.resblock_biggan(x, temb, sd, "blk")
+    y = no.resblock_biggan(x, temb, sd, "blk", up=name == "up", down=name == "down")
     (y * torch.from_numpy(gr["gy"])).sum().backward()
     assert float((x.grad - torch.from_numpy(gr["dx"])).abs().max()) < 1e-5 * float(np.abs(gr["dx"]).max())
     assert float((temb.grad - torch.from_numpy(gr["dtemb"])).abs().max()) < 1e-5 * float(np.abs(gr["dtemb"]).max())

@@ -1,7 +1,8 @@
 """Backward pass of one ``ResnetBlockBigGANpp`` on the HIP operators (minimum slice): the gradient half of the
 reference's ``ScoreModel.train_step`` (model_wrapper.py:147-208, driven by ``SGMSEModule.training_step``, SGMSE_module.py:46-54)
 needs, per res-block, the data and weight gradients of two 3x3 convolutions and the 1x1 shortcut, the backward of two
-GroupNorm + SiLU pairs and of Dense_0(SiLU(temb)).  fp32 storage, NHWC device tensors, plain res-block (no FIR resampling).
+GroupNorm + SiLU pairs and of Dense_0(SiLU(temb)), and - in the up / down blocks - the transposes of the FIR resamplers (which are
+each other up to the gain: ``use_op_fir`` again).  fp32 storage, NHWC device tensors.
 
 * data gradient of a convolution = the forward implicit-GEMM kernel (``use_op_conv``) on the flipped, transposed weights;
 * weight gradient = ``use_op_wgrad`` (pixels as the K of an exact-fp32 MFMA contraction);
@@ -94,6 +95,16 @@ def gn_act_fwd(x, gamma, beta, groups, act=1, eps=1e-6):
     return y
 
 
+def fir(x, up):
+    """upsample_2d / downsample_2d of an fp32 NHWC tensor (``use_op_fir``).  The two are mutual transposes up to the gain:
+    backward(upsample_2d)(g) = 4 downsample_2d(g), backward(downsample_2d)(g) = upsample_2d(g) / 4."""
+    B, H, W, Cc = x.shape
+    H2, W2 = (H * 2, W * 2) if up else (H // 2, W // 2)
+    out = torch.empty(B, H2, W2, Cc, dtype=torch.float32, device=x.device)
+    check(_lib.lib().use_op_fir(_p(x), 0, None, 0, None, _p(out), B, H, W, Cc, int(up), _stream()), "use_op_fir")
+    return out
+
+
 def dense_bwd(g, temb, Wd):
     B, Cout = g.shape
     K = temb.shape[1]
@@ -109,26 +120,29 @@ def colsum(x, scale=1.0):
     return out
 
 
-def resblock_backward(x, h1, temb, gy, W, groups0, groups1):
-    """Gradients of y = (shortcut(x) + Conv_1(SiLU(GN_1(h1)))) / sqrt(2), h1 = Conv_0(SiLU(GN_0(x))) + Dense_0(SiLU(temb)), given gy = dL/dy.
-    x [B,H,W,Cin], h1 [B,H,W,Cout] (the forward's Conv_0 output), gy [B,H,W,Cout]: fp32 NHWC on the GPU, channels multiples of 32
-    (zero-padded; `groups*` count the padding's all-zero groups as well).  W: the block's parameters (torch CPU tensors, padded alike;
-    GroupNorm / Dense parameters also as CUDA tensors under the same keys + '.dev').  Returns dict of gradients."""
+def resblock_backward(x, h1, temb, gy, W, groups0, groups1, up=False, down=False):
+    """Gradients of y = (shortcut(r(x)) + Conv_1(SiLU(GN_1(h1)))) / sqrt(2), h1 = Conv_0(r(SiLU(GN_0(x)))) + Dense_0(SiLU(temb)), given
+    gy = dL/dy; r = identity, or the FIR x2 up / down resampling of the BigGAN block (layerspp.py:286-300).
+    x [B,H,W,Cin], h1 and gy at the block's output resolution [B,H',W',Cout]: fp32 NHWC on the GPU, channels multiples of 32
+    (zero-padded; `groups*` count the padding's all-zero groups as well).  W: the block's parameters (numpy conv weights, padded alike;
+    GroupNorm / Dense parameters as CUDA tensors under the key + '.dev').  Returns dict of gradients."""
     g = {}
-    # Conv_1 (and the shortcut) see gy / sqrt(2)
-    h2_in = h1                                                            # GN_1 + SiLU are recomputed inside the kernels from h1
+    resample = up or down
+    back = (lambda t: fir(t, up=False) * 4.0) if up else (lambda t: fir(t, up=True) * 0.25) if down else (lambda t: t)   # r^T
     a1 = gn_act_fwd(h1, W["GroupNorm_1.weight.dev"], W["GroupNorm_1.bias.dev"], groups1)     # operand of Conv_1's weight gradient (recomputed)
     g["Conv_1.weight"], g["Conv_1.bias"] = conv_wgrad(gy, a1, alpha=SQRT1_2)
     da1 = conv_dgrad(gy, W["Conv_1.weight"], scale=SQRT1_2)
-    dh1, g["GroupNorm_1.weight"], g["GroupNorm_1.bias"] = gn_act_bwd(h2_in, da1, W["GroupNorm_1.weight.dev"], W["GroupNorm_1.bias.dev"], groups1)
+    dh1, g["GroupNorm_1.weight"], g["GroupNorm_1.bias"] = gn_act_bwd(h1, da1, W["GroupNorm_1.weight.dev"], W["GroupNorm_1.bias.dev"], groups1)
     # Dense_0(SiLU(temb)) is broadcast over the pixels of h1
     g["Dense_0.weight"], g["Dense_0.bias"], g["temb"] = dense_bwd(colsum(dh1), temb, W["Dense_0.weight.dev"])
     a0 = gn_act_fwd(x, W["GroupNorm_0.weight.dev"], W["GroupNorm_0.bias.dev"], groups0)
-    g["Conv_0.weight"], g["Conv_0.bias"] = conv_wgrad(dh1, a0)
-    da0 = conv_dgrad(dh1, W["Conv_0.weight"])
-    if "Conv_2.weight" in W:                                              # 1x1 shortcut on the raw input
-        g["Conv_2.weight"], g["Conv_2.bias"] = conv_wgrad(gy, x, ntaps=1, alpha=SQRT1_2)
-        dsc = conv_dgrad(gy, W["Conv_2.weight"], scale=SQRT1_2)
+    a0r = fir(a0, up=up) if resample else a0                              # Conv_0 sees the resampled activation
+    g["Conv_0.weight"], g["Conv_0.bias"] = conv_wgrad(dh1, a0r)
+    da0 = back(conv_dgrad(dh1, W["Conv_0.weight"]))                       # back through the resampler to the input resolution
+    if "Conv_2.weight" in W:                                              # 1x1 shortcut on the (resampled) raw input
+        xr = fir(x, up=up) if resample else x
+        g["Conv_2.weight"], g["Conv_2.bias"] = conv_wgrad(gy, xr, ntaps=1, alpha=SQRT1_2)
+        dsc = back(conv_dgrad(gy, W["Conv_2.weight"], scale=SQRT1_2))
         g["x"], g["GroupNorm_0.weight"], g["GroupNorm_0.bias"] = gn_act_bwd(x, da0, W["GroupNorm_0.weight.dev"], W["GroupNorm_0.bias.dev"], groups0,
                                                                            add=dsc, add_scale=1.0)
     else:                                                                 # identity shortcut
