@@ -218,7 +218,8 @@ int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C
  *                    given), dgamma, dbeta; `work`: 2 B (groups + C) floats of scratch.
  * use_op_gn_act_fwd: y = act(GroupNorm(x)) (the operand of the following convolution's weight gradient, recomputed); work: 2 B groups floats.
  * use_op_colsum:     out[b][c] = scale * sum_p x[b,p,c]            (the gradient reaching Dense_0's output)
- * use_op_dense_bwd:  Dense_0(SiLU(temb)): g [B][Cout] -> dW [Cout][K], db [Cout], dtemb [B][K]. */
+ * use_op_dense_bwd:  Dense_0(SiLU(temb)): g [B][Cout] -> dW [Cout][K], db [Cout], dtemb [B][K].
+ * use_op_attention_bwd: the AttnBlockpp core, out = softmax(q k^T / sqrt(C)) v: dq, dk, dv from dO ([B][N][C] each; work: 2 B N N floats). */
 int use_op_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
                  use_stream_t stream);
 int use_op_gn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, int groups, float eps, int act, const float* add,
@@ -228,6 +229,8 @@ int use_op_gn_act_fwd(const float* x, const float* gamma, const float* beta, int
 int use_op_colsum(const float* x, int B, int HW, int C, float scale, float* out, use_stream_t stream);
 int use_op_dense_bwd(const float* g, const float* temb, const float* Wd, int B, int K, int Cout, float* dW, float* db, float* dtemb,
                      use_stream_t stream);
+int use_op_attention_bwd(const float* q, const float* k, const float* v, const float* dO, float* work, float* dq, float* dk, float* dv, int B, int N,
+                         int C, use_stream_t stream);
 /* ---- wire formats either side of the path, host functions: no device, no handle ----
  * use_wav_read: RIFF/WAVE (PCM 8/16/24/32-bit, IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE) -> interleaved float64 frames scaled like
  *   libsndfile's sf.read (integer PCM / 2^(bits-1)); *samples is malloc'ed, release it with use_free.

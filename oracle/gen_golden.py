@@ -116,6 +116,17 @@ def gen_resblock_grads():
                  **{"d." + k: v.grad.numpy() for k, v in blk.named_parameters()})
 
 
+def gen_attn_grads():
+    """Gradients of AttnBlockpp (gen_attn's module, weights and input) from the reference's backward(); loss = sum(y * gy)."""
+    blk = layerspp.AttnBlockpp(channels=32, skip_rescale=True, init_scale=0.0).eval()
+    fill_module(blk, 9, "attn")
+    x = rnd(3, "attnx", (2, 32, 8, 5)).requires_grad_(True)
+    y = blk(x)
+    gy = rnd(5, "attngy", tuple(y.shape))
+    (y * gy).sum().backward()
+    np.savez(os.path.join(OUT, "attn_grads.npz"), gy=gy.numpy(), dx=x.grad.numpy(), **{"d." + k: v.grad.numpy() for k, v in blk.named_parameters()})
+
+
 def gen_attn():
     blk = layerspp.AttnBlockpp(channels=32, skip_rescale=True, init_scale=0.0).eval()
     w = fill_module(blk, 9, "attn")
@@ -369,7 +380,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    small = {"fir": gen_fir, "resblocks": gen_resblocks, "resblock_grads": gen_resblock_grads, "attn": gen_attn, "samplers": gen_samplers, "samplers_em": gen_samplers_em,
+    small = {"fir": gen_fir, "resblocks": gen_resblocks, "resblock_grads": gen_resblock_grads, "attn": gen_attn, "attn_grads": gen_attn_grads, "samplers": gen_samplers, "samplers_em": gen_samplers_em,
              "refine": gen_refine, "forward_small": gen_forward_small, "both": gen_both,
              "train_loss": gen_train_loss}
     big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1,

@@ -79,3 +79,31 @@ def test_resblock_gradients_match_the_reference_backward(golden_dir, name):
         print(f"[measured] resblock_{name} grad {k}: {e:.3g}")
         worst = max(worst, e)
         assert e < 1e-4, (name, k, e)
+
+
+def test_attention_block_gradients_match_the_reference_backward(golden_dir):
+    """AttnBlockpp (layerspp.py:60-93) on [2,32,8,5]: gradients through use_op_attention_bwd (core), use_op_wgrad / use_op_conv (the four
+    NIN as 1x1 convolutions) and use_op_gn_act_bwd (GroupNorm without activation) against the reference's own backward()."""
+    from universal_speech_enhancement_amd import training_ops as T
+    f = np.load(os.path.join(golden_dir, "attn.npz"))
+    gr = np.load(os.path.join(golden_dir, "attn_grads.npz"))
+    x, gy = torch.from_numpy(f["x"]), torch.from_numpy(gr["gy"])
+    Cc = x.shape[1]
+    W = {k[2:]: f[k] for k in f.files if k.startswith("w.")}
+    for k in ("GroupNorm_0.weight", "GroupNorm_0.bias"):
+        W[k + ".dev"] = torch.from_numpy(W[k]).cuda()
+    g = T.attn_block_backward(_nhwc(x, Cc), _nhwc(gy, Cc), W, min(Cc // 4, 32))
+    torch.cuda.synchronize()
+    checks = {"x": (g["x"].cpu().permute(0, 3, 1, 2), gr["dx"]), "GroupNorm_0.weight": (g["GroupNorm_0.weight"].cpu(), gr["d.GroupNorm_0.weight"]),
+              "GroupNorm_0.bias": (g["GroupNorm_0.bias"].cpu(), gr["d.GroupNorm_0.bias"])}
+    for i in range(4):
+        checks[f"NIN_{i}.W"] = (g[f"NIN_{i}.W"].cpu(), gr[f"d.NIN_{i}.W"]); checks[f"NIN_{i}.b"] = (g[f"NIN_{i}.b"].cpu(), gr[f"d.NIN_{i}.b"])
+    for k, (got, want) in checks.items():
+        want = torch.from_numpy(np.asarray(want))
+        if float(want.abs().max()) < 1e-6:                   # NIN_1.b: a key bias shifts every score of a row alike - its gradient is exactly 0
+            print(f"[measured] attn grad {k}: |got| {float(got.abs().max()):.3g}, |reference| {float(want.abs().max()):.3g} (analytically zero)")
+            assert float(got.abs().max()) < 1e-5, k
+            continue
+        e = float((got - want).abs().max() / want.abs().max())
+        print(f"[measured] attn grad {k}: {e:.3g}")
+        assert e < 1e-4, (k, e)

@@ -191,3 +191,15 @@ def test_oracle_resblock_gradients_match_reference_backward(golden_dir, name):
     for k, v in sd.items():
         want = gr["d." + k[4:]]
         assert float((v.grad - torch.from_numpy(want)).abs().max()) < 1e-5 * float(np.abs(want).max()), k
+
+
+def test_oracle_attention_gradients_match_reference_backward(golden_dir):
+    f = np.load(os.path.join(golden_dir, "attn.npz"))
+    gr = np.load(os.path.join(golden_dir, "attn_grads.npz"))
+    sd = {"blk." + k[2:]: torch.from_numpy(f[k]).requires_grad_(True) for k in f.files if k.startswith("w.")}
+    x = torch.from_numpy(f["x"]).requires_grad_(True)
+    (no.attn_block(x, sd, "blk") * torch.from_numpy(gr["gy"])).sum().backward()
+    assert float((x.grad - torch.from_numpy(gr["dx"])).abs().max()) < 1e-5 * float(np.abs(gr["dx"]).max())
+    for k, v in sd.items():
+        want = gr["d." + k[4:]]
+        assert float((v.grad - torch.from_numpy(want)).abs().max()) < 1e-5 * float(np.abs(want).max()), k

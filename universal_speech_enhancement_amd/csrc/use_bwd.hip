@@ -10,6 +10,7 @@
 //   gn_param_grads        dgamma[c] = sum_b s2, dbeta[c] = sum_b s1
 //   colsum_kernel         out[b][c] = sum_p x[b,p,c]                                          (Dense_0's upstream gradient)
 //   dense_bwd_kernel      Dense_0(act(temb)): dW, db, dtemb
+//   attn_bwd_rows / _cols the attention core: dq, dk, dv from dO (P recomputed)
 //
 // fp32 storage, NHWC ([B][H][W][C]); the contraction of wgrad runs on the matrix pipe in exact fp32 (v_mfma_f32_32x32x2_f32: K = pixels,
 // 2 per instruction, one float per lane and operand - both operands are read coalesced over channels straight from NHWC).
@@ -209,7 +210,75 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(const float* __restrict_
     }
 }
 
+// ---- attention core backward: P = softmax(q k^T / sqrt(C)) recomputed; dP = dO v^T; dS = P (dP - rowsum(P dP)) ---------------------------
+// pass 1, one block per (query i, item): the row i of P and dS (to scratch [B][N][N]) and dq_i = sum_j dS_ij k_j / sqrt(C)
+__global__ __launch_bounds__(128) void attn_bwd_rows_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                            const float* __restrict__ dO, float* __restrict__ P, float* __restrict__ dS,
+                                                            float* __restrict__ dq, int N, int C) {
+    extern __shared__ float sm[];                            // [N] scores -> P, [N] dP -> dS, [C] q_i, [C] dO_i
+    float* sp = sm; float* sd = sm + N; float* qi = sm + 2 * N; float* doi = qi + C;
+    const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const size_t base = (size_t)b * N * C;
+    const float scale = 1.0f / sqrtf((float)C);
+    for (int c = tid; c < C; c += 128) { qi[c] = q[base + (size_t)i * C + c]; doi[c] = dO[base + (size_t)i * C + c]; }
+    __syncthreads();
+    for (int j = tid; j < N; j += 128) {
+        float s = 0.f, d = 0.f;
+        for (int c = 0; c < C; ++c) { s = fmaf(qi[c], k[base + (size_t)j * C + c], s); d = fmaf(doi[c], v[base + (size_t)j * C + c], d); }
+        sp[j] = s * scale; sd[j] = d;
+    }
+    __syncthreads();
+    __shared__ float red[128];
+    float m = -INFINITY;
+    for (int j = tid; j < N; j += 128) m = fmaxf(m, sp[j]);
+    red[tid] = m; __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    m = red[0]; __syncthreads();
+    float sum = 0.f;
+    for (int j = tid; j < N; j += 128) { const float e = expf(sp[j] - m); sp[j] = e; sum += e; }
+    red[tid] = sum; __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float inv = 1.0f / red[0]; __syncthreads();
+    float dot = 0.f;
+    for (int j = tid; j < N; j += 128) { sp[j] *= inv; dot = fmaf(sp[j], sd[j], dot); }
+    red[tid] = dot; __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    dot = red[0]; __syncthreads();
+    for (int j = tid; j < N; j += 128) {
+        sd[j] = sp[j] * (sd[j] - dot);
+        P[((size_t)b * N + i) * N + j] = sp[j]; dS[((size_t)b * N + i) * N + j] = sd[j];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 128) {
+        float a = 0.f;
+        for (int j = 0; j < N; ++j) a = fmaf(sd[j], k[base + (size_t)j * C + c], a);
+        dq[base + (size_t)i * C + c] = a * scale;
+    }
+}
+// pass 2, one block per (key j, item): dk_j = sum_i dS_ij q_i / sqrt(C), dv_j = sum_i P_ij dO_i
+__global__ __launch_bounds__(128) void attn_bwd_cols_kernel(const float* __restrict__ q, const float* __restrict__ dO, const float* __restrict__ P,
+                                                            const float* __restrict__ dS, float* __restrict__ dk, float* __restrict__ dv, int N,
+                                                            int C) {
+    const int j = blockIdx.x, b = blockIdx.y;
+    const size_t base = (size_t)b * N * C;
+    const float scale = 1.0f / sqrtf((float)C);
+    for (int c = threadIdx.x; c < C; c += 128) {
+        float a = 0.f, e = 0.f;
+        for (int i = 0; i < N; ++i) {
+            a = fmaf(dS[((size_t)b * N + i) * N + j], q[base + (size_t)i * C + c], a);
+            e = fmaf(P[((size_t)b * N + i) * N + j], dO[base + (size_t)i * C + c], e);
+        }
+        dk[base + (size_t)j * C + c] = a * scale; dv[base + (size_t)j * C + c] = e;
+    }
+}
+
 // ---- launch wrappers ------------------------------------------------------------------------------------------------------------
+void launch_attention_bwd(const float* q, const float* k, const float* v, const float* dO, float* work, float* dq, float* dk, float* dv, int B,
+                          int N, int C, hipStream_t s) {
+    float* P = work; float* dS = work + (size_t)B * N * N;
+    hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(N, B), dim3(128), (size_t)(2 * N + 2 * C) * 4, s, q, k, v, dO, P, dS, dq, N, C);
+    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(N, B), dim3(128), 0, s, q, dO, P, dS, dk, dv, N, C);
+}
 void launch_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
                   hipStream_t s) {
     const long npix = (long)B * H * W;

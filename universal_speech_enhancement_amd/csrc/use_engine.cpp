@@ -1786,6 +1786,14 @@ int use_op_colsum(const float* x, int B, int HW, int C, float scale, float* out,
     HIPCHK(hipGetLastError());
     return USE_OK;
 }
+int use_op_attention_bwd(const float* q, const float* k, const float* v, const float* dO, float* work, float* dq, float* dk, float* dv, int B, int N,
+                         int C, use_stream_t stream) {
+    if (!q || !k || !v || !dO || !work || !dq || !dk || !dv || B < 1 || N < 1 || C < 1) return fail(USE_E_INVALID, "use_op_attention_bwd: bad argument");
+    if ((size_t)(2 * N + 2 * C) * 4 > 60000) return fail(USE_E_INVALID, "use_op_attention_bwd: N + C too large for one row in LDS");
+    launch_attention_bwd(q, k, v, dO, work, dq, dk, dv, B, N, C, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
 int use_op_dense_bwd(const float* g, const float* temb, const float* Wd, int B, int K, int Cout, float* dW, float* db, float* dtemb, use_stream_t stream) {
     if (!g || !temb || !Wd || !dW || !db || !dtemb) return fail(USE_E_INVALID, "use_op_dense_bwd: null tensor");
     launch_dense_bwd(g, temb, Wd, B, K, Cout, dW, db, dtemb, (hipStream_t)stream);

@@ -170,6 +170,9 @@ void launch_gn_act_bwd(const float* x, const float* dy, const float* mean, const
 void launch_gn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int B, int HW, int C,
                        int G, float* y, hipStream_t s);
 void launch_colsum(const float* x, int B, int HW, int C, float scale, float* out, hipStream_t s);       // out[b][c] = scale * sum_p x[b,p,c]
+// attention core backward (q, k, v, dO, dq, dk, dv: [B][N][C] fp32; work: 2 B N N floats)
+void launch_attention_bwd(const float* q, const float* k, const float* v, const float* dO, float* work, float* dq, float* dk, float* dv, int B,
+                          int N, int C, hipStream_t s);
 void launch_dense_bwd(const float* g, const float* temb, const float* Wd, int B, int K, int Cout, float* dW, float* db, float* dtemb, hipStream_t s);
 
 // ---- SDE updates (complex64 as float2, fp32 arithmetic) ----

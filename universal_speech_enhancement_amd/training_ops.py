@@ -149,3 +149,48 @@ def resblock_backward(x, h1, temb, gy, W, groups0, groups1, up=False, down=False
         g["x"], g["GroupNorm_0.weight"], g["GroupNorm_0.bias"] = gn_act_bwd(x, da0, W["GroupNorm_0.weight.dev"], W["GroupNorm_0.bias.dev"], groups0,
                                                                            add=gy, add_scale=SQRT1_2)
     return g
+
+
+def attention_core(q, k, v):
+    """softmax(q k^T / sqrt(C)) v on [B,N,C] fp32 tensors (``use_op_attention``)."""
+    B, N, Cc = q.shape
+    out = torch.empty_like(q)
+    check(_lib.lib().use_op_attention(_p(q), _p(k), _p(v), _p(out), 0, B, N, Cc, _stream()), "use_op_attention")
+    return out
+
+
+def attention_core_bwd(q, k, v, dO):
+    B, N, Cc = q.shape
+    work = torch.empty(2 * B * N * N, dtype=torch.float32, device=q.device)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    check(_lib.lib().use_op_attention_bwd(_p(q), _p(k), _p(v), _p(dO), _p(work), _p(dq), _p(dk), _p(dv), B, N, Cc, _stream()), "use_op_attention_bwd")
+    return dq, dk, dv
+
+
+def attn_block_backward(x, gy, W, groups):
+    """Gradients of AttnBlockpp (layerspp.py:60-93): y = (x + NIN_3(softmax(q k^T / sqrt(C)) v)) / sqrt(2), q, k, v = NIN_0..2(GroupNorm(x)).
+    x, gy [B,H,W,C] fp32 NHWC on the GPU (C a multiple of 32); W: 'NIN_i.W' numpy [C][C] (the reference's [cin][cout]) and 'NIN_i.b',
+    GroupNorm parameters as CUDA tensors under key + '.dev'.  The forward activations (h, q, k, v, attention output) are recomputed
+    with the forward operators.  NIN = 1x1 convolution with weight W^T."""
+    B, H, Wd, Cc = x.shape
+    N = H * Wd
+    g = {}
+    h = gn_act_fwd(x, W["GroupNorm_0.weight.dev"], W["GroupNorm_0.bias.dev"], groups, act=0)
+    wt = [np.ascontiguousarray(np.asarray(W[f"NIN_{i}.W"]).T) for i in range(4)]            # conv weights [cout][cin]
+    q, k, v = (conv_fwd(h, wt[i], bias=W[f"NIN_{i}.b"], ntaps=1) for i in range(3))
+    a = attention_core(q.view(B, N, Cc), k.view(B, N, Cc), v.view(B, N, Cc)).view(B, H, Wd, Cc)
+    # y = (x + NIN_3(a)) / sqrt(2)
+    dw3, g["NIN_3.b"] = conv_wgrad(gy, a, ntaps=1, alpha=SQRT1_2)
+    g["NIN_3.W"] = dw3.t().contiguous()                                                   # back to the reference's [cin][cout]
+    da = conv_fwd(gy, np.ascontiguousarray(np.asarray(W["NIN_3.W"])), scale=SQRT1_2, ntaps=1)    # dgrad of a 1x1: the transposed matrix
+    dq, dk, dv = attention_core_bwd(q.view(B, N, Cc), k.view(B, N, Cc), v.view(B, N, Cc), da.view(B, N, Cc))
+    dh = None
+    for i, d in enumerate((dq, dk, dv)):
+        d4 = d.view(B, H, Wd, Cc)
+        dwi, g[f"NIN_{i}.b"] = conv_wgrad(d4, h, ntaps=1)
+        g[f"NIN_{i}.W"] = dwi.t().contiguous()
+        di = conv_fwd(d4, np.ascontiguousarray(np.asarray(W[f"NIN_{i}.W"])), ntaps=1)
+        dh = di if dh is None else dh + di
+    g["x"], g["GroupNorm_0.weight"], g["GroupNorm_0.bias"] = gn_act_bwd(x, dh, W["GroupNorm_0.weight.dev"], W["GroupNorm_0.bias.dev"], groups, act=0,
+                                                                       add=gy, add_scale=SQRT1_2)
+    return g
