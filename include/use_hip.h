@@ -205,6 +205,13 @@ typedef struct use_conv_op {
     long long* stats;
 } use_conv_op;
 int use_op_conv(const use_conv_op* c, use_stream_t stream);
+/* use_op_conv_dev: the same operator for the training path (reference SGMSE_module.py:46-54 -> model_wrapper.py:147-208, where the
+ *   parameters are nn.Parameters on the device and change every optimiser step): c->w / c->bias are DEVICE fp32 tensors, laid out for
+ *   the kernels by a kernel on `stream` into the caller's workspace (use_op_conv_dev_workspace(c) bytes); no allocation, no
+ *   synchronisation, no fused shortcut (XC0 = XC1 = 0).  w_mode: 0 = conv weight [Cout][Cin][taps]; 1 = data gradient of the conv whose
+ *   weight is c->w [Cin][Cout][taps] (the kernel sees w'[co][ci][tap] = w[ci][co][taps-1-tap]); 2 = NIN matrix [Cin][Cout] (ntaps 1). */
+size_t use_op_conv_dev_workspace(const use_conv_op* c);
+int use_op_conv_dev(const use_conv_op* c, int w_mode, void* work, size_t work_bytes, use_stream_t stream);
 int use_op_fir(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B, int H, int W, int C, int up,
                use_stream_t stream);
 int use_op_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int N, int C, use_stream_t stream);

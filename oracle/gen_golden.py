@@ -358,6 +358,48 @@ def gen_train_loss(model=None):
     np.savez(os.path.join(OUT, "train_loss.npz"), start=1234, num_frames=64, weights_seed=1234, z_seed=55, **out)
 
 
+def gen_train_grads(model=None):
+    """The gradient half of training_step (SGMSE_module.py:46-54): loss = ScoreModel.train_step(batch) exactly as in gen_train_loss
+    (same clips, t, z, start, weights), then the reference's own loss.backward().  Stored per parameter: the L2 norm of the gradient
+    ("n.<name>", float64); the full gradient of every tensor of <= 10000 elements ("g.<name>"); and, of the large ones, the leading
+    [:4, :4, ...] corner ("c.<name>").  Case a: condition noisy / mse; case b: condition both / sde_input denoised / mae."""
+    import src.models.components.sgmse.model_wrapper as MW
+    for tag, cond, sde_in, L, arch, loss_type in (("a", "noisy", "noisy", 12000, tw.LARGE, "mse"),
+                                                   ("b", "both", "denoised", 8000, tw.LARGE_BOTH, "mae")):
+        clean = torch.from_numpy(tnoise.synth_noisy_speech(2, L, seed=91))
+        noisy = 0.8 * clean + 0.2 * torch.from_numpy(tnoise.synth_noisy_speech(2, L, seed=92))
+        fake = 0.9 * clean + 0.1 * torch.from_numpy(tnoise.synth_noisy_speech(2, L, seed=93))
+        t = torch.tensor([0.31, 0.87], dtype=torch.float32)
+        z = torch.from_numpy(tnoise.complex_normal(55, "train_z_" + tag, (2, 1, 512, 64)))
+        start = 1234
+        sd = tw.make_state_dict(1234, **arch)
+        torch.manual_seed(0)
+        m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition=cond, loss_type=loss_type, n_fft=1022,
+                       hop_length=160, num_frames=64, window="hann", sde_input=sde_in).eval()
+        m.score_net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        o_rand, o_randn, o_unif = torch.rand, torch.randn_like, MW.np.random.uniform
+        torch.rand = lambda *a, **k: (t - m.t_eps) / (m.sde.T - m.t_eps)
+        torch.randn_like = lambda like, **k: z.clone()
+        MW.np.random.uniform = lambda lo, hi: start
+        try:
+            loss = m.train_step({"clean": clean.clone(), "perturbed": noisy.clone(), "fake": fake.clone()})
+        finally:
+            torch.rand, torch.randn_like, MW.np.random.uniform = o_rand, o_randn, o_unif
+        loss.backward()
+        out = {"loss": np.float64(loss.item())}
+        for k, p in m.score_net.named_parameters():
+            if p.grad is None:
+                continue                                                   # the Fourier projection's W is not trained
+            g = p.grad.detach()
+            out["n." + k] = np.float64(g.double().norm().item())
+            if g.numel() <= 10000:
+                out["g." + k] = g.numpy().astype(np.float32)
+            else:
+                out["c." + k] = g[:4, :4].contiguous().numpy().astype(np.float32)
+        np.savez(os.path.join(OUT, f"train_grads_{tag}.npz"), weights_seed=1234, z_seed=55, start=start, num_frames=64, t=t.numpy(),
+                 crc=tw.weights_checksum(sd), **out)
+
+
 def gen_refine(model=None):
     """LSGAN refine stage: NCSNPP_Wrapper(n_fft=1022, hop=160, num_frames=480) = NCSNpp(discriminative=True)
     between STFT glue (GAN/generator/ncsnpp/model_wrapper.py:19-121, configs/model/LSGAN.yaml:46-53)."""
@@ -382,7 +424,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     small = {"fir": gen_fir, "resblocks": gen_resblocks, "resblock_grads": gen_resblock_grads, "attn": gen_attn, "attn_grads": gen_attn_grads, "samplers": gen_samplers, "samplers_em": gen_samplers_em,
              "refine": gen_refine, "forward_small": gen_forward_small, "both": gen_both,
-             "train_loss": gen_train_loss}
+             "train_loss": gen_train_loss, "train_grads": gen_train_grads}
     big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1,
            "sample_denoised": gen_sample_denoised}
     todo = [a.only] if a.only else list(small) + list(big)

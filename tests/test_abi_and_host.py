@@ -222,3 +222,28 @@ def test_train_step_refuses_frame_counts_it_would_have_to_pad():
     m = ScoreModel(backbone="none", sde="ouve", condition="noisy", sde_input="noisy", n_fft=1022, hop_length=160, num_frames=100)
     with pytest.raises(ValueError, match="multiple of 64"):
         m.train_step({"clean": torch.zeros(1, 20000), "perturbed": torch.zeros(1, 20000)})
+
+
+def test_training_entry_points_refuse_without_a_tape_or_a_gpu():
+    """SGMSEModule.training_step (reference SGMSE_module.py:46-54) needs trainable parameters (they are created frozen); the taped
+    network has no CPU implementation and says so; configure_optimizers mirrors the reference's partial-factory contract (:26-40)."""
+    import functools
+    import torch
+    from universal_speech_enhancement_amd.SGMSE_module import SGMSEModule
+    from universal_speech_enhancement_amd.sgmse.backbones import BackboneRegistry
+    from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel
+    m = ScoreModel(backbone="ncsnpp6M", sde="ouve", condition="noisy", sde_input="noisy", n_fft=254, hop_length=64, num_frames=64, precision="fp32")
+    mod = SGMSEModule(Score=m, optimizer=functools.partial(torch.optim.SGD, lr=0.1))
+    assert not m.score_net.trainable
+    with pytest.raises(RuntimeError, match="frozen"):
+        mod.training_step({"clean": torch.zeros(1, 6000), "perturbed": torch.zeros(1, 6000)}, 0)
+    cfg = mod.configure_optimizers()
+    assert list(cfg[0]) == ["optimizer"] and isinstance(cfg[0]["optimizer"], torch.optim.SGD)
+    assert sum(p.numel() for g in cfg[0]["optimizer"].param_groups for p in g["params"]) == sum(p.numel() for p in m.parameters())
+    with pytest.raises(RuntimeError, match="optimizer"):
+        SGMSEModule(Score=m).configure_optimizers()
+    net = BackboneRegistry.get_by_name("ncsnpp6M")(input_channels=4, precision="fp32")
+    net.requires_grad_(True)
+    assert net.trainable
+    with pytest.raises(_lib.UseHipError):
+        net(torch.zeros(1, 2, 64, 64, dtype=torch.complex64), torch.ones(1))

@@ -768,7 +768,7 @@ def test_train_step_loss_matches_reference(golden_dir, tag, cond, sde_in, arch, 
     """SURVEY 8f4, forward half: ScoreModel.train_step (model_wrapper.py:147-208) -- what the reference module's validation_step /
     test_step log (SGMSE_module.py:56-63) -- through the HIP score network, against losses computed by the reference with the same
     t, z and crop start: random-excerpt and zero-padding branches, conditions noisy / both, mse / mae.  fp32: 2e-4 relative;
-    bf16 within 3 % (sum of 65 k squared errors).  Optimisation itself is not served: training_step raises."""
+    bf16 within 3 % (sum of 65 k squared errors).  With frozen parameters training_step refuses (the taped path: test_hip_training.py)."""
     from universal_speech_enhancement_amd.SGMSE_module import SGMSEModule
     from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel
     g = dict(np.load(os.path.join(golden_dir, "train_loss.npz")))
@@ -788,7 +788,7 @@ def test_train_step_loss_matches_reference(golden_dir, tag, cond, sde_in, arch, 
     mod = SGMSEModule(Score=m)
     v = mod.validation_step(batch)                                       # random t, z, start: finite, same order of magnitude
     assert torch.isfinite(v) and 0.1 * want < float(v) < 10 * want
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):                                    # frozen parameters (tests/test_hip_training.py covers the taped path)
         mod.training_step(batch, 0)
 
 

@@ -129,6 +129,37 @@ def test_train_loss_matches_reference(golden_dir, tag, cond, sde_in, arch, losse
         assert abs(float(loss) - float(g[f"loss_{tag}_{lt}"])) < 2e-5 * float(g[f"loss_{tag}_{lt}"]), (lt, float(loss))
 
 
+def test_train_gradients_match_reference_backward(golden_dir):
+    """SURVEY 8f4 (gradient half): autograd through the oracle's train-step loss against the reference's own loss.backward()
+    (train_grads_a.npz: per-parameter gradient norms, small tensors in full, corners of the large ones) - the fixture the HIP
+    training path is held to (tests/test_hip_training.py)."""
+    g = _load(golden_dir, "train_grads_a.npz")
+    gl = _load(golden_dir, "train_loss.npz")
+    sd_np = tw.make_state_dict(int(g["weights_seed"]), **tw.LARGE)
+    assert tw.weights_checksum(sd_np) == str(g["crc"])
+    sd = {k: (v.requires_grad_(True) if k != "all_modules.0.W" else v) for k, v in no.to_torch(sd_np).items()}
+    z = torch.from_numpy(tnoise.complex_normal(int(g["z_seed"]), "train_z_a", (2, 1, 512, 64)))
+    torch.set_num_threads(usable_cores())
+    loss = so.score_model_train_loss(lambda x, t: no.ncsnpp_forward(sd, x, t), torch.from_numpy(gl["clean_a"]), torch.from_numpy(gl["noisy_a"]),
+                                     torch.from_numpy(g["t"]), z, int(g["start"]), condition="noisy", sde_input="noisy",
+                                     num_frames=int(g["num_frames"]), loss_type="mse")
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5 * float(g["loss"])
+    loss.backward()
+    n = 0
+    for key in g:
+        kind, _, name = key.partition(".")
+        if kind not in ("n", "g", "c") or name.endswith("NIN_1.b"):          # NIN_1.b: analytically zero gradient (rounding only)
+            continue
+        got = sd[name].grad
+        if kind == "n":
+            assert abs(float(got.double().norm()) - float(g[key])) < 2e-5 * float(g[key]), name
+            n += 1
+        else:
+            have = got if kind == "g" else got[:4, :4]
+            assert float((have - torch.from_numpy(g[key])).abs().max()) < 1e-4 * float(np.abs(g[key]).max()), name
+    assert n > 500
+
+
 @pytest.mark.slow
 def test_sample_e2e_matches_reference(golden_dir, large_sd):
     g = _load(golden_dir, "sample_e2e.npz")

@@ -67,6 +67,24 @@ class SGMSEModule(torch.nn.Module):
         """Reference :61-63."""
         return self.get_score_loss(batch)
 
-    def training_step(self, *a, **k):
-        raise NotImplementedError("optimisation is outside the scope of the MI355X sampling library: there are no backward kernels "
-                                  "(the loss itself is available: validation_step / Score.train_step)")
+    def training_step(self, batch: dict, batch_idx: int = 0) -> torch.Tensor:
+        """Reference :46-54 (there the value is also logged): the score-matching loss WITH its tape, for ``loss.backward()`` and an
+        optimiser step.  The score network's parameters are created frozen (the sampling path never differentiates); training needs
+        ``module.Score.score_net.requires_grad_(True)`` first, on the GPU."""
+        if not getattr(self.Score.score_net, "trainable", False):
+            raise RuntimeError("training_step: the score network's parameters are frozen - call Score.score_net.requires_grad_(True) "
+                               "(validation_step / test_step give the loss without a tape)")
+        with torch.enable_grad():
+            return self.get_score_loss(batch)
+
+    def configure_optimizers(self):
+        """Reference :26-40: ``optimizer(params=Score.parameters())`` and ``scheduler(optimizer=...)`` from the constructor's partials,
+        in Lightning's dictionary layout (the monitor key is the reference's)."""
+        if self.optimizer is None:
+            raise RuntimeError("configure_optimizers: SGMSEModule was built without an optimizer factory")
+        opt = self.optimizer(params=self.Score.parameters())
+        if self.scheduler is None:
+            return [{"optimizer": opt}]
+        return [{"optimizer": opt,
+                 "lr_scheduler": {"scheduler": self.scheduler(optimizer=opt), "monitor": "val/loss_Score_epoch", "interval": "epoch",
+                                  "frequency": 1}}]

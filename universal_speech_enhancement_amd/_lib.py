@@ -88,6 +88,8 @@ SYMBOLS = {
     "use_timesteps": (_i, [_i, _f, C.POINTER(_f)]),
     "use_conv_bench": (_i, [C.POINTER(UseConvCase), _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "use_op_conv": (_i, [C.POINTER(UseConvOp), _vp]),
+    "use_op_conv_dev_workspace": (C.c_size_t, [C.POINTER(UseConvOp)]),
+    "use_op_conv_dev": (_i, [C.POINTER(UseConvOp), _i, _vp, C.c_size_t, _vp]),
     "use_op_fir": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "use_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "use_op_gn_finalize": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _i, _vp]),

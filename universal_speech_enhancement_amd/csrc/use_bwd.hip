@@ -272,6 +272,38 @@ __global__ __launch_bounds__(128) void attn_bwd_cols_kernel(const float* __restr
     }
 }
 
+// ---- device-side weight packing (training: the parameters live in HBM and change every step) ----------------------------------------
+// Writes the two layouts the convolution kernels read (use_kernels.h: plain [cout][tap][cin] and, when ck > 0, slab-major
+// [tap][cin/ck][cout_pad][ck] with the 16-byte pieces of a row swizzled by the row) from an fp32 parameter tensor in HBM.
+// mode 0: conv weight [cout][cin][taps];  mode 1: the data-gradient operand of a conv weight W[cin_op... = cout_fwd][cout_op = cin_fwd][taps],
+// i.e. w'[co][ci][tap] = W[ci][co][taps-1-tap];  mode 2: NIN matrix [cin][cout] (layers.py:639-650).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_dev_kernel(const float* __restrict__ src, int mode, int cout, int cin, int ntaps, int cout_pad, int ck,
+                                                            T* __restrict__ dst, T* __restrict__ dstb) {
+    const long total = (long)ntaps * cout_pad * cin;
+    constexpr int vec = 16 / (int)sizeof(T);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ci = (int)(idx % cin);
+        const int tap = (int)((idx / cin) % ntaps);
+        const int co = (int)(idx / ((long)cin * ntaps));
+        float v = 0.f;
+        if (co < cout)
+            v = mode == 0 ? src[((size_t)co * cin + ci) * ntaps + tap]
+              : mode == 1 ? src[((size_t)ci * cout + co) * ntaps + (ntaps - 1 - tap)]
+                          : src[(size_t)ci * cout + co];
+        const T o = (T)v;
+        dst[idx] = o;                                                         // idx == (co * ntaps + tap) * cin + ci
+        if (ck) {
+            const int e = ci % ck;
+            dstb[(((size_t)tap * (cin / ck) + ci / ck) * cout_pad + co) * ck + (((e / vec) ^ ((co >> 2) & 3)) * vec + e % vec)] = o;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void pad_bias_kernel(const float* __restrict__ b, int cout, int cout_pad, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < cout_pad) out[i] = (b && i < cout) ? b[i] : 0.f;
+}
+
 // ---- launch wrappers ------------------------------------------------------------------------------------------------------------
 void launch_attention_bwd(const float* q, const float* k, const float* v, const float* dO, float* work, float* dq, float* dk, float* dv, int B,
                           int N, int C, hipStream_t s) {
@@ -320,6 +352,16 @@ void launch_colsum(const float* x, int B, int HW, int C, float scale, float* out
 }
 void launch_dense_bwd(const float* g, const float* temb, const float* Wd, int B, int K, int Cout, float* dW, float* db, float* dtemb, hipStream_t s) {
     hipLaunchKernelGGL(dense_bwd_kernel, dim3(1), dim3(256), 0, s, g, temb, Wd, B, K, Cout, dW, db, dtemb);
+}
+
+void launch_pack_conv_dev(const float* src, int mode, int cout, int cin, int ntaps, int cout_pad, int dtype, int ck, void* dst, void* dstb,
+                          const float* bias, float* bias_out, hipStream_t s) {
+    const long total = (long)ntaps * cout_pad * cin;
+    const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 8192);
+    if (dtype == DT_F32)       hipLaunchKernelGGL(pack_conv_dev_kernel<float>, dim3(blocks), dim3(256), 0, s, src, mode, cout, cin, ntaps, cout_pad, dstb ? ck : 0, (float*)dst, (float*)dstb);
+    else if (dtype == DT_BF16) hipLaunchKernelGGL(pack_conv_dev_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, src, mode, cout, cin, ntaps, cout_pad, dstb ? ck : 0, (__bf16*)dst, (__bf16*)dstb);
+    else                       hipLaunchKernelGGL(pack_conv_dev_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, src, mode, cout, cin, ntaps, cout_pad, dstb ? ck : 0, (_Float16*)dst, (_Float16*)dstb);
+    hipLaunchKernelGGL(pad_bias_kernel, dim3((cout_pad + 255) / 256), dim3(256), 0, s, bias, cout, cout_pad, bias_out);
 }
 
 }  // namespace use

@@ -1734,6 +1734,44 @@ int use_op_conv(const use_conv_op* c, use_stream_t stream) {
     cleanup();
     return rc;
 }
+// use_op_conv with the weights already in HBM (fp32 parameter tensors: the training path, where they change every step) and a
+// caller-provided workspace: the weights are laid out by a kernel on `stream`, nothing is allocated and nothing synchronises.
+static size_t conv_dev_layout(const use_conv_op* c, size_t* wbytes, bool* slab, int* cout_pad) {
+    const int Cin = c->C0 + c->C1, ntaps = c->ntaps == 1 ? 1 : 9;
+    *cout_pad = c->Cout <= 32 ? 32 : (c->Cout + 127) / 128 * 128;
+    *wbytes = ((size_t)ntaps * *cout_pad * Cin * dtype_size(c->dtype) + 255) / 256 * 256;
+    *slab = ntaps == 9 && *cout_pad % 128 == 0 && Cin % conv_v4_chunk(c->dtype) == 0;
+    return *wbytes * (*slab ? 2 : 1) + (size_t)*cout_pad * 4;
+}
+size_t use_op_conv_dev_workspace(const use_conv_op* c) {
+    if (!c || c->C0 < 1 || c->Cout < 1) return 0;
+    size_t wb; bool slab; int cp;
+    return conv_dev_layout(c, &wb, &slab, &cp);
+}
+int use_op_conv_dev(const use_conv_op* c, int w_mode, void* work, size_t work_bytes, use_stream_t stream) {
+    if (!c || c->B < 1 || c->H < 1 || c->W < 1 || c->C0 < 1 || c->Cout < 1 || !c->src0 || !c->w || !c->out || !work) return fail(USE_E_INVALID, "use_op_conv_dev: bad argument");
+    const int dt = c->dtype, odt = c->out_dtype;
+    if ((dt != DT_F32 && dt != DT_BF16 && dt != DT_F16) || (odt != DT_F32 && odt != DT_BF16 && odt != DT_F16)) return fail(USE_E_INVALID, "use_op_conv_dev: bad dtype");
+    if (w_mode < 0 || w_mode > 2 || (w_mode == 2 && c->ntaps != 1)) return fail(USE_E_INVALID, "use_op_conv_dev: bad weight layout %d", w_mode);
+    const int Cin = c->C0 + c->C1, ntaps = c->ntaps == 1 ? 1 : 9;
+    if (Cin % 32 != 0 || (c->C1 && c->C0 % 32)) return fail(USE_E_INVALID, "use_op_conv_dev: channel counts must be multiples of 32 (zero-pad)");
+    if (c->XC0 || c->XC1 || c->x0 || c->w2) return fail(USE_E_INVALID, "use_op_conv_dev: no fused shortcut in this form");
+    size_t wbytes; bool slab; int cout_pad;
+    if (conv_dev_layout(c, &wbytes, &slab, &cout_pad) > work_bytes) return fail(USE_E_INVALID, "use_op_conv_dev: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    char* dw = (char*)work; char* dwb = slab ? dw + wbytes : nullptr;
+    float* dbias = (float*)(dw + wbytes * (slab ? 2 : 1));
+    launch_pack_conv_dev((const float*)c->w, w_mode, c->Cout, Cin, ntaps, cout_pad, dt, conv_v4_chunk(dt), dw, dwb, (const float*)c->bias, dbias, s);
+    ConvArgs a{};
+    a.B = c->B; a.H = c->H; a.W = c->W; a.Cout = c->Cout; a.ntaps = ntaps; a.in_dtype = dt; a.out_dtype = odt;
+    a.src0 = c->src0; a.src1 = c->C1 ? c->src1 : nullptr; a.C0 = c->C0; a.C1 = c->C1; a.coef = c->coef; a.act = c->act;
+    a.w = dw; a.wb = dwb; a.cout_pad = cout_pad;
+    a.bias = dbias; a.temb = c->temb; a.temb_bstride = c->Cout; a.res = c->res; a.out_scale = c->out_scale;
+    a.out = c->out; a.stats = c->stats;
+    launch_conv(a, s);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
 int use_op_fir(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B, int H, int W, int C, int up,
                use_stream_t stream) {
     if (!src || (!out_act && !out_raw) || B < 1 || H < 1 || W < 1 || C < 1) return fail(USE_E_INVALID, "use_op_fir: bad argument");

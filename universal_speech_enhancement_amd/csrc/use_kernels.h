@@ -174,6 +174,9 @@ void launch_colsum(const float* x, int B, int HW, int C, float scale, float* out
 void launch_attention_bwd(const float* q, const float* k, const float* v, const float* dO, float* work, float* dq, float* dk, float* dv, int B,
                           int N, int C, hipStream_t s);
 void launch_dense_bwd(const float* g, const float* temb, const float* Wd, int B, int K, int Cout, float* dW, float* db, float* dtemb, hipStream_t s);
+// fp32 parameter tensor in HBM -> the kernels' weight layouts (plain, and slab-major when dstb != nullptr) + the zero-padded bias
+void launch_pack_conv_dev(const float* src, int mode, int cout, int cin, int ntaps, int cout_pad, int dtype, int ck, void* dst, void* dstb,
+                          const float* bias, float* bias_out, hipStream_t s);
 
 // ---- SDE updates (complex64 as float2, fp32 arithmetic) ----
 struct RngRef { const unsigned long long* state; unsigned draw; };  // state[0]=seed, state[1]=draw base

@@ -140,6 +140,25 @@ class NCSNpp(nn.Module):
         """Call after modifying parameters in place (``load_state_dict`` is tracked automatically)."""
         self._engine_dirty, self._weight_file = True, None
 
+    @property
+    def trainable(self) -> bool:
+        """True once ``requires_grad_(True)`` was called on the module (parameters are created frozen: the sampling path never
+        differentiates)."""
+        return any(p.requires_grad for p in self.parameters())
+
+    def forward_train(self, x: torch.Tensor, time_cond: torch.Tensor = None) -> torch.Tensor:
+        """The same network with a tape (fp32, operators of libuse_hip.so forward and backward: ``training.ncsnpp_forward_train``);
+        what ``forward`` runs when gradients are enabled and the parameters are trainable.  The sampling engine's weight copy is marked
+        stale: an optimiser step is assumed to follow."""
+        from ...training import ncsnpp_forward_train
+        P = dict(self.named_parameters())
+        if any(not p.is_cuda for p in P.values()):
+            from ...hip_engine import UseHipError
+            raise UseHipError("NCSN++ (HIP) training needs the parameters on the GPU (module.to('cuda')): there is no CPU implementation")
+        self._engine_dirty, self._weight_file = True, None
+        return ncsnpp_forward_train(P, x, time_cond, self.ch_mult, self.num_res_blocks, conditional=self.conditional,
+                                    scale_by_sigma=self.scale_by_sigma)
+
     def forward(self, x: torch.Tensor, time_cond: torch.Tensor = None) -> torch.Tensor:
         nin = self.input_channels // 2
         if x.dim() != 4 or x.shape[1] != nin:
@@ -151,6 +170,8 @@ class NCSNpp(nn.Module):
             raise UseHipError("NCSN++ (HIP) needs CUDA/ROCm tensors: the network has no CPU implementation")
         if self.conditional and time_cond is None:
             raise ValueError("a conditional NCSN++ needs time_cond")
+        if torch.is_grad_enabled() and self.trainable:
+            return self.forward_train(x, time_cond)
         eng = self.engine(x.shape[2], x.device)
         if nin == 1:
             return eng.forward(x, None, time_cond if (self.conditional or self.scale_by_sigma) else None)

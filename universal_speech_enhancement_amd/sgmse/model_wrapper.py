@@ -56,14 +56,21 @@ class ScoreModel(SpectralGlue, nn.Module):
             raise NotImplementedError(f"loss_type {self.loss_type!r}")
         return torch.mean(0.5 * torch.sum(losses.reshape(losses.shape[0], -1), dim=-1))
 
-    @torch.no_grad()
     def train_step(self, batch, t=None, z=None, start=None):
         """The denoising-score-matching loss of one batch (reference :147-208): crop / pad to ``target_len``, spectrograms,
-        t ~ U(t_eps, T), x_t = mean(x0, t, y) + std(t) z, err = score(x_t) std + z, ``_loss(err)``.  **Forward only** -- this is
-        what ``validation_step`` / ``test_step`` of the reference module log (SGMSE_module.py:56-63); the library has no backward
-        kernels, so the value carries no gradient and ``SGMSEModule.training_step`` refuses to optimise with it.
+        t ~ U(t_eps, T), x_t = mean(x0, t, y) + std(t) z, err = score(x_t) std + z, ``_loss(err)``.
+        With gradients enabled and a trainable score network (``score_net.requires_grad_(True)``) the network runs on the
+        differentiable fp32 HIP operators (``training.ncsnpp_forward_train``) and the loss carries the tape -- what
+        ``SGMSEModule.training_step`` returns (SGMSE_module.py:46-54).  Otherwise (``validation_step`` / ``test_step``,
+        SGMSE_module.py:56-63, or frozen parameters) it is the forward-only value from the sampling engine.
         ``t`` [B], ``z`` complex [B,1,F,T] and ``start`` override the random draws (the reference draws them from the global
         numpy / torch generators)."""
+        if torch.is_grad_enabled() and getattr(self.score_net, "trainable", False):
+            return self._train_step(batch, t, z, start)
+        with torch.no_grad():
+            return self._train_step(batch, t, z, start)
+
+    def _train_step(self, batch, t, z, start):
         import numpy as np
         import torch.nn.functional as F
         x, y = batch["clean"], batch["perturbed"]
