@@ -1,0 +1,42 @@
+"""Time one optimisation step (train_step forward + backward + Adam) of NCSN++ large on the differentiable HIP operators.
+usage: python scripts/train_step_bench.py [B] [num_frames] [steps]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+NF = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+torch.manual_seed(0)
+m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition="noisy", n_fft=510, hop_length=128, num_frames=NF,
+               window="hann", sde_input="noisy", precision="fp32").cuda()
+m.score_net.requires_grad_(True)
+opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+L = (NF - 1) * 128 + 4000
+clean = torch.randn(B, L, device="cuda") * 0.1
+batch = {"clean": clean, "perturbed": clean + 0.05 * torch.randn_like(clean)}
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    loss = m.train_step(batch)
+    loss.backward()
+    opt.step()
+    return loss
+
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(STEPS):
+    loss = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / STEPS
+print(f"train step B={B} frames={NF}: {dt * 1e3:.1f} ms/step  ({B * NF / dt:.0f} frames/s)  loss {float(loss.detach()):.4g}  "
+      f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")

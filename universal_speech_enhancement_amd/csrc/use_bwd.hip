@@ -166,6 +166,166 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict
     }
 }
 
+// ---- sliced forms (C % 4 == 0, C <= 1024): grid (pixel slices, B); a block covers `ppi` pixels per iteration with C/4 threads per
+// pixel (16-byte loads along the channels), folds its pixel lanes through LDS and leaves one fp64 partial per (slice, channel | group);
+// a one-block-per-item kernel sums the slices.  These replace the one-block-per-(item, group | 64 channels) kernels above, which leave
+// the chip idle on the full-resolution maps (8 blocks for a 128-channel map of 4 items).
+__host__ __device__ inline int gn_slices(int HW, int C) {
+    const int ppi = 256 / (C / 4);
+    int n = HW / (ppi * 4);
+    return n < 1 ? 1 : n > GN_MAX_SLICES ? GN_MAX_SLICES : n;
+}
+
+__global__ __launch_bounds__(256) void gn_stats_part_kernel(const float* __restrict__ x, int HW, int C, int G, double* __restrict__ part) {
+    __shared__ float sh[2][1024];
+    __shared__ double ch[2][1024];
+    const int tpp = C / 4, ppi = 256 / tpp, t = threadIdx.x, b = blockIdx.y, ns = gridDim.x;
+    const int per = (HW + ns - 1) / ns, lo = blockIdx.x * per, hi = lo + per < HW ? lo + per : HW;
+    const bool on = t < tpp * ppi;
+    const int pl = t / tpp, c4 = (t % tpp) * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    if (on)
+        for (int p = lo + pl; p < hi; p += ppi) {
+            const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * HW + p) * C + c4);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            q[0] = fmaf(v.x, v.x, q[0]); q[1] = fmaf(v.y, v.y, q[1]); q[2] = fmaf(v.z, v.z, q[2]); q[3] = fmaf(v.w, v.w, q[3]);
+        }
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sh[0][pl * C + c4 + k] = s[k]; sh[1][pl * C + c4 + k] = q[k]; }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        double a = 0.0, e = 0.0;
+        for (int l = 0; l < ppi; ++l) { a += sh[0][l * C + c]; e += sh[1][l * C + c]; }
+        ch[0][c] = a; ch[1][c] = e;
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int g = t; g < G; g += 256) {
+        double a = 0.0, e = 0.0;
+        for (int k = 0; k < cpg; ++k) { a += ch[0][g * cpg + k]; e += ch[1][g * cpg + k]; }
+        double* o = part + (((size_t)b * ns + blockIdx.x) * G + g) * 2;
+        o[0] = a; o[1] = e;
+    }
+}
+__global__ __launch_bounds__(256) void gn_stats_fin_kernel(const double* __restrict__ part, int ns, int BG, int G, double n, float eps,
+                                                           float* __restrict__ mean, float* __restrict__ rstd) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= BG) return;
+    const int b = i / G, g = i % G;
+    double a = 0.0, e = 0.0;
+    for (int sl = 0; sl < ns; ++sl) { const double* o = part + (((size_t)b * ns + sl) * G + g) * 2; a += o[0]; e += o[1]; }
+    const double m = a / n;
+    double var = e / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m; rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(256) void gn_act_bwd_part_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int HW, int C, int G, double* __restrict__ part) {
+    __shared__ float sh[2][1024];
+    const int tpp = C / 4, ppi = 256 / tpp, t = threadIdx.x, b = blockIdx.y, ns = gridDim.x, cpg = C / G;
+    const int per = (HW + ns - 1) / ns, lo = blockIdx.x * per, hi = lo + per < HW ? lo + per : HW;
+    const bool on = t < tpp * ppi;
+    const int pl = t / tpp, c4 = (t % tpp) * 4;
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (on) {
+        float mu[4], rs[4], gm[4], bt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = (c4 + k) / cpg;
+            mu[k] = mean[b * G + g]; rs[k] = rstd[b * G + g]; gm[k] = gamma[c4 + k]; bt[k] = beta[c4 + k];
+        }
+        for (int p = lo + pl; p < hi; p += ppi) {
+            const size_t i = ((size_t)b * HW + p) * C + c4;
+            const float4 xv = *reinterpret_cast<const float4*>(x + i), dv = *reinterpret_cast<const float4*>(dy + i);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xs[k] - mu[k]) * rs[k];
+                const float du = ds[k] * act_grad<ACT>(fmaf(gm[k], xh, bt[k]));
+                a1[k] += du; a2[k] = fmaf(du, xh, a2[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sh[0][pl * C + c4 + k] = a1[k]; sh[1][pl * C + c4 + k] = a2[k]; }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        double a = 0.0, e = 0.0;
+        for (int l = 0; l < ppi; ++l) { a += sh[0][l * C + c]; e += sh[1][l * C + c]; }
+        double* o = part + (((size_t)b * ns + blockIdx.x) * C + c) * 2;
+        o[0] = a; o[1] = e;
+    }
+}
+// one block per item: s1 / s2 per channel (sum of the slices) and the group means m1 / m2 of gamma s1, gamma s2
+__global__ __launch_bounds__(256) void gn_act_bwd_fin_kernel(const double* __restrict__ part, const float* __restrict__ gamma, int ns, int HW, int C,
+                                                             int G, float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ m1,
+                                                             float* __restrict__ m2) {
+    __shared__ double ch[2][1024];
+    const int b = blockIdx.x, t = threadIdx.x, cpg = C / G;
+    for (int c = t; c < C; c += 256) {
+        double a = 0.0, e = 0.0;
+        for (int sl = 0; sl < ns; ++sl) { const double* o = part + (((size_t)b * ns + sl) * C + c) * 2; a += o[0]; e += o[1]; }
+        s1[(size_t)b * C + c] = (float)a; s2[(size_t)b * C + c] = (float)e;
+        ch[0][c] = a * gamma[c]; ch[1][c] = e * gamma[c];
+    }
+    __syncthreads();
+    const double inv = 1.0 / ((double)HW * cpg);
+    for (int g = t; g < G; g += 256) {
+        double a = 0.0, e = 0.0;
+        for (int k = 0; k < cpg; ++k) { a += ch[0][g * cpg + k]; e += ch[1][g * cpg + k]; }
+        m1[b * G + g] = (float)(a * inv); m2[b * G + g] = (float)(e * inv);
+    }
+}
+template <bool ACT>
+__global__ __launch_bounds__(256) void gn_act_bwd_apply4_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ m1,
+                                                                const float* __restrict__ m2, const float* __restrict__ add, float add_scale, int HW,
+                                                                int C, int G, float* __restrict__ dx, long n4) {
+    const int cpg = C / G, c4n = C / 4;
+    for (long i4 = (long)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * 256) {
+        const int c4 = (int)(i4 % c4n) * 4, b = (int)(i4 / ((long)HW * c4n));
+        const size_t i = (size_t)i4 * 4;
+        const float4 xv = *reinterpret_cast<const float4*>(x + i), dv = *reinterpret_cast<const float4*>(dy + i);
+        float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (add) av = *reinterpret_cast<const float4*>(add + i);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w}, as[4] = {av.x, av.y, av.z, av.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c4 + k, g = c / cpg;
+            const float rs = rstd[b * G + g], xh = (xs[k] - mean[b * G + g]) * rs, gm = gamma[c];
+            const float du = ds[k] * act_grad<ACT>(fmaf(gm, xh, beta[c]));
+            o[k] = fmaf(add_scale, as[k], rs * (gm * du - m1[b * G + g] - xh * m2[b * G + g]));
+        }
+        *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+template <bool ACT>
+__global__ __launch_bounds__(256) void gn_act_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C, int G,
+                                                          float* __restrict__ y, long n4) {
+    const int cpg = C / G, c4n = C / 4;
+    for (long i4 = (long)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * 256) {
+        const int c4 = (int)(i4 % c4n) * 4, b = (int)(i4 / ((long)HW * c4n));
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)i4 * 4);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c4 + k, g = c / cpg;
+            const float u = fmaf(gamma[c], (xs[k] - mean[b * G + g]) * rstd[b * G + g], beta[c]);
+            o[k] = ACT ? u / (1.0f + expf(-u)) : u;
+        }
+        *reinterpret_cast<float4*>(y + (size_t)i4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 __global__ void gn_param_grads_kernel(const float* __restrict__ s1, const float* __restrict__ s2, int B, int C, float* __restrict__ dgamma,
                                       float* __restrict__ dbeta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -322,14 +482,37 @@ void launch_wgrad(const float* dy, const float* x, float* dw, float* db, int B, 
     hipLaunchKernelGGL(wgrad_kernel, dim3((Cout + 31) / 32, (Cin + 31) / 32, ntaps * nslices), dim3(256), 0, s, dy, x, dw, db, B, H, W, Cout, Cin,
                        ntaps, nslices, alpha);
 }
-void launch_gn_stats(const float* x, int B, int HW, int C, int G, float eps, float* mean, float* rstd, hipStream_t s) {
+static bool gn_sliced(int C, int G) { return C % 4 == 0 && C <= 1024 && G <= 1024; }
+size_t gn_workspace_floats(int B, int C, int G) {
+    // [fp64 partials: 2 B slices max(C, G)] [mean, rstd: 2 B G] [s1, s2: 2 B C] [m1, m2: 2 B G]
+    return (size_t)4 * B * GN_MAX_SLICES * std::max(C, G) + (size_t)4 * B * G + (size_t)2 * B * C;
+}
+void launch_gn_stats(const float* x, int B, int HW, int C, int G, float eps, float* mean, float* rstd, double* part, hipStream_t s) {
+    if (part && gn_sliced(C, G)) {
+        const int ns = gn_slices(HW, C);
+        hipLaunchKernelGGL(gn_stats_part_kernel, dim3(ns, B), dim3(256), 0, s, x, HW, C, G, part);
+        hipLaunchKernelGGL(gn_stats_fin_kernel, dim3((B * G + 255) / 256), dim3(256), 0, s, part, ns, B * G, G, (double)HW * (C / G), eps, mean, rstd);
+        return;
+    }
     hipLaunchKernelGGL(gn_stats_kernel, dim3(B * G), dim3(256), 0, s, x, HW, C, G, eps, mean, rstd);
 }
 void launch_gn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
-                       const float* add, float add_scale, int B, int HW, int C, int G, float* s1, float* s2, float* dx, float* dgamma,
-                       float* dbeta, hipStream_t s) {
-    const dim3 gr((C + 63) / 64, B);
+                       const float* add, float add_scale, int B, int HW, int C, int G, float* s1, float* s2, float* m12, double* part, float* dx,
+                       float* dgamma, float* dbeta, hipStream_t s) {
     const long n = (long)B * HW * C;
+    if (part && m12 && gn_sliced(C, G)) {
+        const int ns = gn_slices(HW, C);
+        float* m1 = m12; float* m2 = m12 + (size_t)B * G;
+        const unsigned blocks = (unsigned)std::min<long>((n / 4 + 255) / 256, 8192);
+        if (act) hipLaunchKernelGGL(gn_act_bwd_part_kernel<true>, dim3(ns, B), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, part);
+        else     hipLaunchKernelGGL(gn_act_bwd_part_kernel<false>, dim3(ns, B), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, part);
+        hipLaunchKernelGGL(gn_act_bwd_fin_kernel, dim3(B), dim3(256), 0, s, part, gamma, ns, HW, C, G, s1, s2, m1, m2);
+        if (act) hipLaunchKernelGGL(gn_act_bwd_apply4_kernel<true>, dim3(blocks), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, m1, m2, add, add_scale, HW, C, G, dx, n / 4);
+        else     hipLaunchKernelGGL(gn_act_bwd_apply4_kernel<false>, dim3(blocks), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, m1, m2, add, add_scale, HW, C, G, dx, n / 4);
+        hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 127) / 128), dim3(128), 0, s, s1, s2, B, C, dgamma, dbeta);
+        return;
+    }
+    const dim3 gr((C + 63) / 64, B);
     const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 4096);
     if (act) {
         hipLaunchKernelGGL(gn_act_bwd_reduce<true>, gr, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, s1, s2);
@@ -343,6 +526,12 @@ void launch_gn_act_bwd(const float* x, const float* dy, const float* mean, const
 void launch_gn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int B, int HW, int C,
                        int G, float* y, hipStream_t s) {
     const long n = (long)B * HW * C;
+    if (C % 4 == 0) {
+        const unsigned blocks = (unsigned)std::min<long>((n / 4 + 255) / 256, 8192);
+        if (act) hipLaunchKernelGGL(gn_act_fwd4_kernel<true>, dim3(blocks), dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y, n / 4);
+        else     hipLaunchKernelGGL(gn_act_fwd4_kernel<false>, dim3(blocks), dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y, n / 4);
+        return;
+    }
     const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 4096);
     if (act) hipLaunchKernelGGL(gn_act_fwd_kernel<true>, dim3(blocks), dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y, n);
     else     hipLaunchKernelGGL(gn_act_fwd_kernel<false>, dim3(blocks), dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y, n);

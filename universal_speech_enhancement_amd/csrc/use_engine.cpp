@@ -1799,22 +1799,30 @@ int use_op_wgrad(const float* dy, const float* x, float* dw, float* db, int B, i
     HIPCHK(hipGetLastError());
     return USE_OK;
 }
+// workspace of the two GroupNorm operators, in floats (8-byte aligned): [fp64 slice partials][mean, rstd][s1, s2][m1, m2]
+size_t use_op_gn_workspace(int B, int C, int groups) { return (B < 1 || C < 1 || groups < 1) ? 0 : gn_workspace_floats(B, C, groups); }
 int use_op_gn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, int groups, float eps, int act, const float* add,
                       float add_scale, int B, int HW, int C, float* work, float* dx, float* dgamma, float* dbeta, use_stream_t stream) {
     if (!x || !dy || !gamma || !beta || !work || !dx || !dgamma || !dbeta || groups < 1 || C % groups) return fail(USE_E_INVALID, "use_op_gn_act_bwd: bad argument");
+    if ((uintptr_t)work % 8) return fail(USE_E_INVALID, "use_op_gn_act_bwd: workspace must be 8-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    float* mean = work; float* rstd = work + (size_t)B * groups; float* s1 = rstd + (size_t)B * groups; float* s2 = s1 + (size_t)B * C;
-    launch_gn_stats(x, B, HW, C, groups, eps, mean, rstd, s);
-    launch_gn_act_bwd(x, dy, mean, rstd, gamma, beta, act, add, add_scale, B, HW, C, groups, s1, s2, dx, dgamma, dbeta, s);
+    double* part = (double*)work;
+    float* mean = work + (size_t)4 * B * GN_MAX_SLICES * std::max(C, groups); float* rstd = mean + (size_t)B * groups;
+    float* s1 = rstd + (size_t)B * groups; float* s2 = s1 + (size_t)B * C; float* m12 = s2 + (size_t)B * C;
+    launch_gn_stats(x, B, HW, C, groups, eps, mean, rstd, part, s);
+    launch_gn_act_bwd(x, dy, mean, rstd, gamma, beta, act, add, add_scale, B, HW, C, groups, s1, s2, m12, part, dx, dgamma, dbeta, s);
     HIPCHK(hipGetLastError());
     return USE_OK;
 }
 int use_op_gn_act_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, int act, int B, int HW, int C, float* work,
                       float* y, use_stream_t stream) {
     if (!x || !gamma || !beta || !work || !y || groups < 1 || C % groups) return fail(USE_E_INVALID, "use_op_gn_act_fwd: bad argument");
+    if ((uintptr_t)work % 8) return fail(USE_E_INVALID, "use_op_gn_act_fwd: workspace must be 8-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    launch_gn_stats(x, B, HW, C, groups, eps, work, work + (size_t)B * groups, s);
-    launch_gn_act_fwd(x, work, work + (size_t)B * groups, gamma, beta, act, B, HW, C, groups, y, s);
+    double* part = (double*)work;
+    float* mean = work + (size_t)4 * B * GN_MAX_SLICES * std::max(C, groups); float* rstd = mean + (size_t)B * groups;
+    launch_gn_stats(x, B, HW, C, groups, eps, mean, rstd, part, s);
+    launch_gn_act_fwd(x, mean, rstd, gamma, beta, act, B, HW, C, groups, y, s);
     HIPCHK(hipGetLastError());
     return USE_OK;
 }

@@ -162,11 +162,14 @@ void launch_score_out(const float* pyr, int pc, const float* t, int t_stride, co
 // ---- backward kernels of one res-block (use_bwd.hip; fp32 storage, NHWC): the gradient half of train_step, minimum slice ----
 void launch_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
                   hipStream_t s);                            // dW [Cout][Cin][ntaps] (reference layout), db [Cout] or null
-void launch_gn_stats(const float* x, int B, int HW, int C, int G, float eps, float* mean, float* rstd, hipStream_t s);
+// part (fp64 scratch of gn_workspace_floats) = nullptr: the one-block-per-(item, group) forms
+void launch_gn_stats(const float* x, int B, int HW, int C, int G, float eps, float* mean, float* rstd, double* part, hipStream_t s);
+constexpr int GN_MAX_SLICES = 256;            // pixel slices per item of the sliced GroupNorm reductions (fp64 partials per slice)
+size_t gn_workspace_floats(int B, int C, int G);
 // dx = d/dx of act(GroupNorm(x)) against dy, + add_scale * add (or add == null); s1 / s2: [B][C] scratch; dgamma / dbeta [C]
 void launch_gn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
-                       const float* add, float add_scale, int B, int HW, int C, int G, float* s1, float* s2, float* dx, float* dgamma,
-                       float* dbeta, hipStream_t s);
+                       const float* add, float add_scale, int B, int HW, int C, int G, float* s1, float* s2, float* m12, double* part, float* dx,
+                       float* dgamma, float* dbeta, hipStream_t s);
 void launch_gn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int B, int HW, int C,
                        int G, float* y, hipStream_t s);
 void launch_colsum(const float* x, int B, int HW, int C, float scale, float* out, hipStream_t s);       // out[b][c] = scale * sum_p x[b,p,c]

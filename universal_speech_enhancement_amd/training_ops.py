@@ -78,7 +78,7 @@ def conv_wgrad(dy, x, ntaps=9, alpha=1.0, with_bias=True):
 
 def gn_act_bwd(x, dy, gamma, beta, groups, act=1, add=None, add_scale=1.0, eps=1e-6):
     B, H, W, Cc = x.shape
-    work = torch.empty(2 * B * (groups + Cc), dtype=torch.float32, device=x.device)
+    work = torch.empty(_lib.lib().use_op_gn_workspace(B, Cc, groups), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     dg, dbt = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
     check(_lib.lib().use_op_gn_act_bwd(_p(x), _p(dy), _p(gamma), _p(beta), groups, eps, act, _p(add), add_scale, B, H * W, Cc, _p(work), _p(dx),
@@ -89,7 +89,7 @@ def gn_act_bwd(x, dy, gamma, beta, groups, act=1, add=None, add_scale=1.0, eps=1
 def gn_act_fwd(x, gamma, beta, groups, act=1, eps=1e-6):
     """act(GroupNorm(x)) - the operand of the following convolution's weight gradient, recomputed from the stored pre-activation."""
     B, H, W, Cc = x.shape
-    work = torch.empty(2 * B * groups, dtype=torch.float32, device=x.device)
+    work = torch.empty(_lib.lib().use_op_gn_workspace(B, Cc, groups), dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
     check(_lib.lib().use_op_gn_act_fwd(_p(x), _p(gamma), _p(beta), groups, eps, act, B, H * W, Cc, _p(work), _p(y), _stream()), "use_op_gn_act_fwd")
     return y
