@@ -221,14 +221,17 @@ int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C
  * model_wrapper.py:147-208 / SGMSE_module.py:46-54).  fp32 NHWC device tensors.  The data gradient of a convolution is use_op_conv
  * itself on the flipped, transposed weights; these are the rest:
  * use_op_wgrad:      dW[co][ci][tap] = alpha * sum dY[b,p,co] X[b,p+tap,ci] (reference weight layout), db[co] = alpha * sum dY (or null).
+ *                    work: use_op_wgrad_workspace(...) floats of scratch for the tiled kernel (per-slice partial tiles, summed without
+ *                    atomics), or null for the small-tile kernel with atomic accumulation.
  * use_op_gn_act_bwd: gradient of act(GroupNorm(groups, eps)(x)) (act: 0 none, 1 SiLU) against dy: dx (+ add_scale * add when add is
  *                    given), dgamma, dbeta; `work`: use_op_gn_workspace(B, C, groups) floats of scratch, 8-byte aligned.
  * use_op_gn_act_fwd: y = act(GroupNorm(x)) (the operand of the following convolution's weight gradient, recomputed); same workspace.
  * use_op_colsum:     out[b][c] = scale * sum_p x[b,p,c]            (the gradient reaching Dense_0's output)
  * use_op_dense_bwd:  Dense_0(SiLU(temb)): g [B][Cout] -> dW [Cout][K], db [Cout], dtemb [B][K].
  * use_op_attention_bwd: the AttnBlockpp core, out = softmax(q k^T / sqrt(C)) v: dq, dk, dv from dO ([B][N][C] each; work: 2 B N N floats). */
+size_t use_op_wgrad_workspace(int B, int H, int W, int Cout, int Cin, int ntaps);
 int use_op_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
-                 use_stream_t stream);
+                 float* work, size_t work_floats, use_stream_t stream);
 size_t use_op_gn_workspace(int B, int C, int groups);
 int use_op_gn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, int groups, float eps, int act, const float* add,
                       float add_scale, int B, int HW, int C, float* work, float* dx, float* dgamma, float* dbeta, use_stream_t stream);

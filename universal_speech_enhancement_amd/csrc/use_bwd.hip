@@ -72,6 +72,116 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy
     }
 }
 
+// ---- weight gradient, tiled form ---------------------------------------------------------------------------------------------------
+// One workgroup = a 64 co x 64 ci tile of dW for ALL taps (4 waves as 2 x 2, each 32 x 32 x taps accumulators: 144 registers for a 3x3)
+// over one slice of the pixels.  Pixels are walked in chunks of RH rows x CW columns (RH CW <= 64, RH | H so that a chunk stays inside one
+// image): the chunk of dY ([64 px][64 co]) and the (RH + 2) x (CW + 2) halo patch of X ([px][64 ci], zero outside the image) are staged in
+// LDS once and feed 9 MFMAs (one per tap: the same dY operand against the patch shifted by the tap) per pixel pair -
+// v_mfma_f32_32x32x2_f32, exact fp32.  Slices write their tile to part[slice][co][ci][tap] (the reference's weight layout);
+// wgrad_reduce_kernel sums the slices (deterministic: no atomics).  Two workgroups per CU overlap each other's staging.
+constexpr int WG_PX = 64, WG_T = 64, WG_PATCH = 198;          // pixels per chunk, tile edge, largest patch (RH, CW) = (1, 64) or (64, 1)
+constexpr int WG_SMEM = (WG_PX * WG_T + WG_PATCH * WG_T) * 4 + WG_PX * 4;
+
+struct WgradPlan { int RH, CW, chunks_x, units, per_slice, nslices; };
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                            float* __restrict__ bpart, int B, int H, int W, int Cout, int Cin, WgradPlan q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* dyS = reinterpret_cast<float*>(smem);                        // [64 px][64 co]
+    float* xS = dyS + WG_PX * WG_T;                                     // [(RH + 2)(CW + 2) px][64 ci]
+    int* pofs = reinterpret_cast<int*>(xS + WG_PATCH * WG_T);           // patch pixel of chunk pixel j (centre tap), -1: not a pixel
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int tiles_ci = (Cin + WG_T - 1) / WG_T;
+    const int co0 = (blockIdx.x / tiles_ci) * WG_T, ci0 = (blockIdx.x % tiles_ci) * WG_T;
+    const int wm = wave >> 1, wn = wave & 1;                            // this wave's 32 x 32 quadrant of the tile
+    const int PWp = q.CW + 2, npatch = (q.RH + 2) * PWp, nchunk = q.RH * q.CW;
+    if (t < WG_PX) pofs[t] = t < nchunk ? (t / q.CW + 1) * PWp + t % q.CW + 1 : -1;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    float bsum = 0.f;
+    const int u_lo = blockIdx.y * q.per_slice, u_hi = min(u_lo + q.per_slice, q.units);
+    const int rows_per_img = H / q.RH;
+    for (int u = u_lo; u < u_hi; ++u) {
+        const int cx = u % q.chunks_x, rr = u / q.chunks_x;             // column chunk, row chunk (over all images)
+        const int b = rr / rows_per_img, y0 = (rr % rows_per_img) * q.RH, x0 = cx * q.CW;
+        __syncthreads();                                                // the previous chunk's MFMAs are done with the LDS
+        for (int e = t; e < WG_PX * (WG_T / 4); e += 256) {             // dY chunk
+            const int j = e / (WG_T / 4), c4 = (e % (WG_T / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int r = j / q.CW, cxx = x0 + j % q.CW;
+            if (j < nchunk && cxx < W && co0 + c4 < Cout)
+                v = *reinterpret_cast<const float4*>(dy + (((size_t)b * H + y0 + r) * W + cxx) * Cout + co0 + c4);
+            *reinterpret_cast<float4*>(dyS + j * WG_T + c4) = v;
+        }
+        if (NT == 9) {
+            for (int e = t; e < npatch * (WG_T / 4); e += 256) {        // X patch with a one-pixel halo, zero outside the image
+                const int pp = e / (WG_T / 4), c4 = (e % (WG_T / 4)) * 4;
+                const int yy = y0 + pp / PWp - 1, xx = x0 + pp % PWp - 1;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W && ci0 + c4 < Cin)
+                    v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + yy) * W + xx) * Cin + ci0 + c4);
+                *reinterpret_cast<float4*>(xS + pp * WG_T + c4) = v;
+            }
+        } else {
+            for (int e = t; e < WG_PX * (WG_T / 4); e += 256) {         // 1x1: the chunk's own pixels, stored at their patch positions
+                const int j = e / (WG_T / 4), c4 = (e % (WG_T / 4)) * 4;
+                const int r = j / q.CW, cxx = x0 + j % q.CW;
+                if (j < nchunk) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (cxx < W && ci0 + c4 < Cin) v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + y0 + r) * W + cxx) * Cin + ci0 + c4);
+                    *reinterpret_cast<float4*>(xS + ((r + 1) * PWp + j % q.CW + 1) * WG_T + c4) = v;
+                }
+            }
+        }
+        __syncthreads();
+        const float* aP = dyS + wm * 32 + l31;
+        const float* bP = xS + wn * 32 + l31;
+#pragma unroll 4
+        for (int j0 = 0; j0 < WG_PX; j0 += 2) {
+            const int j = j0 + hh;                                      // this lane's pixel of the pair (the k index of the MFMA)
+            const int po = pofs[j];
+            float a = aP[j * WG_T];
+            if (po < 0) a = 0.f;                                        // beyond the chunk (RH CW < 64): contributes nothing
+            const int pb = po < 0 ? PWp + 1 : po;
+            bsum += a;
+            if (NT == 9) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float bv = bP[(pb + (k / 3 - 1) * PWp + (k % 3 - 1)) * WG_T];
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[k], 0, 0, 0);      // D[co][ci] += sum_k dY[k][co] X[k + tap][ci]
+                }
+            } else {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bP[pb * WG_T], acc[0], 0, 0, 0);
+            }
+        }
+    }
+    float* o = part + (size_t)blockIdx.y * Cout * Cin * NT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, ci = ci0 + wn * 32 + l31;
+        if (co < Cout && ci < Cin) {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) o[((size_t)co * Cin + ci) * NT + k] = acc[k][r];
+        }
+    }
+    if (bpart && ci0 == 0 && wn == 0) {                                // bias gradient: column sums of dY, once per co tile and slice
+        bsum += __shfl_xor(bsum, 32);
+        if (hh == 0 && co0 + wm * 32 + l31 < Cout) bpart[(size_t)blockIdx.y * Cout + co0 + wm * 32 + l31] = bsum;
+    }
+}
+// out[i] = alpha * sum over the slices of part[slice][i]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nslices, long n, float alpha, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float a = 0.f;
+        for (int sl = 0; sl < nslices; ++sl) a += part[(size_t)sl * n + i];
+        out[i] = a * alpha;
+    }
+}
+
 // ---- GroupNorm statistics: one block per (item, group) -----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int HW, int C, int G, float eps, float* __restrict__ mean,
                                                        float* __restrict__ rstd) {
@@ -172,7 +282,7 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict
 // the chip idle on the full-resolution maps (8 blocks for a 128-channel map of 4 items).
 __host__ __device__ inline int gn_slices(int HW, int C) {
     const int ppi = 256 / (C / 4);
-    int n = HW / (ppi * 4);
+    int n = HW / (ppi * 8);
     return n < 1 ? 1 : n > GN_MAX_SLICES ? GN_MAX_SLICES : n;
 }
 
@@ -209,17 +319,19 @@ __global__ __launch_bounds__(256) void gn_stats_part_kernel(const float* __restr
         o[0] = a; o[1] = e;
     }
 }
-__global__ __launch_bounds__(256) void gn_stats_fin_kernel(const double* __restrict__ part, int ns, int BG, int G, double n, float eps,
-                                                           float* __restrict__ mean, float* __restrict__ rstd) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= BG) return;
-    const int b = i / G, g = i % G;
+// one wave per (item, group): the slices are summed across the lanes
+__global__ __launch_bounds__(64) void gn_stats_fin_kernel(const double* __restrict__ part, int ns, int G, double n, float eps,
+                                                          float* __restrict__ mean, float* __restrict__ rstd) {
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
     double a = 0.0, e = 0.0;
-    for (int sl = 0; sl < ns; ++sl) { const double* o = part + (((size_t)b * ns + sl) * G + g) * 2; a += o[0]; e += o[1]; }
-    const double m = a / n;
-    double var = e / n - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[i] = (float)m; rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    for (int sl = threadIdx.x; sl < ns; sl += 64) { const double* o = part + (((size_t)b * ns + sl) * G + g) * 2; a += o[0]; e += o[1]; }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); e += __shfl_xor(e, o); }
+    if (threadIdx.x == 0) {
+        const double m = a / n;
+        double var = e / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[blockIdx.x] = (float)m; rstd[blockIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 template <bool ACT>
@@ -261,24 +373,23 @@ __global__ __launch_bounds__(256) void gn_act_bwd_part_kernel(const float* __res
         o[0] = a; o[1] = e;
     }
 }
-// one block per item: s1 / s2 per channel (sum of the slices) and the group means m1 / m2 of gamma s1, gamma s2
-__global__ __launch_bounds__(256) void gn_act_bwd_fin_kernel(const double* __restrict__ part, const float* __restrict__ gamma, int ns, int HW, int C,
-                                                             int G, float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ m1,
-                                                             float* __restrict__ m2) {
-    __shared__ double ch[2][1024];
-    const int b = blockIdx.x, t = threadIdx.x, cpg = C / G;
-    for (int c = t; c < C; c += 256) {
+// one wave per (item, group): s1 / s2 per channel (the slices summed across the lanes) and the group means m1 / m2 of gamma s1, gamma s2
+__global__ __launch_bounds__(64) void gn_act_bwd_fin_kernel(const double* __restrict__ part, const float* __restrict__ gamma, int ns, int HW, int C,
+                                                            int G, float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ m1,
+                                                            float* __restrict__ m2) {
+    const int b = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G;
+    double ga = 0.0, ge = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+        const int c = g * cpg + k;
         double a = 0.0, e = 0.0;
-        for (int sl = 0; sl < ns; ++sl) { const double* o = part + (((size_t)b * ns + sl) * C + c) * 2; a += o[0]; e += o[1]; }
-        s1[(size_t)b * C + c] = (float)a; s2[(size_t)b * C + c] = (float)e;
-        ch[0][c] = a * gamma[c]; ch[1][c] = e * gamma[c];
+        for (int sl = threadIdx.x; sl < ns; sl += 64) { const double* o = part + (((size_t)b * ns + sl) * C + c) * 2; a += o[0]; e += o[1]; }
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); e += __shfl_xor(e, o); }
+        if (threadIdx.x == 0) { s1[(size_t)b * C + c] = (float)a; s2[(size_t)b * C + c] = (float)e; }
+        ga += a * gamma[c]; ge += e * gamma[c];
     }
-    __syncthreads();
-    const double inv = 1.0 / ((double)HW * cpg);
-    for (int g = t; g < G; g += 256) {
-        double a = 0.0, e = 0.0;
-        for (int k = 0; k < cpg; ++k) { a += ch[0][g * cpg + k]; e += ch[1][g * cpg + k]; }
-        m1[b * G + g] = (float)(a * inv); m2[b * G + g] = (float)(e * inv);
+    if (threadIdx.x == 0) {
+        const double inv = 1.0 / ((double)HW * cpg);
+        m1[blockIdx.x] = (float)(ga * inv); m2[blockIdx.x] = (float)(ge * inv);
     }
 }
 template <bool ACT>
@@ -471,8 +582,44 @@ void launch_attention_bwd(const float* q, const float* k, const float* v, const 
     hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(N, B), dim3(128), (size_t)(2 * N + 2 * C) * 4, s, q, k, v, dO, P, dS, dq, N, C);
     hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(N, B), dim3(128), 0, s, q, dO, P, dS, dk, dv, N, C);
 }
+static WgradPlan wgrad_plan(int B, int H, int W, int Cout, int Cin) {
+    WgradPlan q;
+    q.CW = std::min(W, WG_PX);
+    q.RH = std::min(WG_PX / q.CW, H);
+    while (H % q.RH) --q.RH;                                          // a chunk stays inside one image
+    q.chunks_x = (W + q.CW - 1) / q.CW;
+    q.units = B * (H / q.RH) * q.chunks_x;
+    const int tiles = ((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T);
+    int ns = std::max(1, 1024 / tiles);                               // about 4 workgroups per CU in total ...
+    ns = std::min(ns, std::max(1, q.units / 4));                      // ... of at least 4 chunks each
+    q.per_slice = (q.units + ns - 1) / ns;
+    q.nslices = (q.units + q.per_slice - 1) / q.per_slice;
+    return q;
+}
+size_t wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin, int ntaps) {
+    if (Cout % 4 || Cin % 4) return 0;
+    const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin);
+    return (size_t)q.nslices * ((size_t)Cout * Cin * ntaps + Cout);
+}
 void launch_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
-                  hipStream_t s) {
+                  float* work, hipStream_t s) {
+    if (work && Cout % 4 == 0 && Cin % 4 == 0) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
+            attr = true;
+        }
+        const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin);
+        const long n = (long)Cout * Cin * ntaps;
+        float* part = work; float* bpart = work + (size_t)q.nslices * n;
+        const dim3 grid(((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T), q.nslices);
+        if (ntaps == 9) hipLaunchKernelGGL(wgrad_tile_kernel<9>, grid, dim3(256), WG_SMEM, s, dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, q);
+        else            hipLaunchKernelGGL(wgrad_tile_kernel<1>, grid, dim3(256), WG_SMEM, s, dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, q);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, s, part, q.nslices, n, alpha, dw);
+        if (db) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, bpart, q.nslices, (long)Cout, alpha, db);
+        return;
+    }
     const long npix = (long)B * H * W;
     int nslices = (int)std::min<long>(64, std::max<long>(1, npix / 4096));     // pixel slices (atomic accumulation when > 1)
     if (nslices > 1) {
@@ -491,7 +638,7 @@ void launch_gn_stats(const float* x, int B, int HW, int C, int G, float eps, flo
     if (part && gn_sliced(C, G)) {
         const int ns = gn_slices(HW, C);
         hipLaunchKernelGGL(gn_stats_part_kernel, dim3(ns, B), dim3(256), 0, s, x, HW, C, G, part);
-        hipLaunchKernelGGL(gn_stats_fin_kernel, dim3((B * G + 255) / 256), dim3(256), 0, s, part, ns, B * G, G, (double)HW * (C / G), eps, mean, rstd);
+        hipLaunchKernelGGL(gn_stats_fin_kernel, dim3(B * G), dim3(64), 0, s, part, ns, G, (double)HW * (C / G), eps, mean, rstd);
         return;
     }
     hipLaunchKernelGGL(gn_stats_kernel, dim3(B * G), dim3(256), 0, s, x, HW, C, G, eps, mean, rstd);
@@ -506,7 +653,7 @@ void launch_gn_act_bwd(const float* x, const float* dy, const float* mean, const
         const unsigned blocks = (unsigned)std::min<long>((n / 4 + 255) / 256, 8192);
         if (act) hipLaunchKernelGGL(gn_act_bwd_part_kernel<true>, dim3(ns, B), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, part);
         else     hipLaunchKernelGGL(gn_act_bwd_part_kernel<false>, dim3(ns, B), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, part);
-        hipLaunchKernelGGL(gn_act_bwd_fin_kernel, dim3(B), dim3(256), 0, s, part, gamma, ns, HW, C, G, s1, s2, m1, m2);
+        hipLaunchKernelGGL(gn_act_bwd_fin_kernel, dim3(B * G), dim3(64), 0, s, part, gamma, ns, HW, C, G, s1, s2, m1, m2);
         if (act) hipLaunchKernelGGL(gn_act_bwd_apply4_kernel<true>, dim3(blocks), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, m1, m2, add, add_scale, HW, C, G, dx, n / 4);
         else     hipLaunchKernelGGL(gn_act_bwd_apply4_kernel<false>, dim3(blocks), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, m1, m2, add, add_scale, HW, C, G, dx, n / 4);
         hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 127) / 128), dim3(128), 0, s, s1, s2, B, C, dgamma, dbeta);

@@ -1792,10 +1792,14 @@ int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C
 }
 
 // ---- backward operators (fp32 NHWC device tensors; SURVEY 8f4 minimum slice: one res-block) ----
+size_t use_op_wgrad_workspace(int B, int H, int W, int Cout, int Cin, int ntaps) {
+    return (B < 1 || H < 1 || W < 1 || Cout < 1 || Cin < 1) ? 0 : wgrad_workspace_floats(B, H, W, Cout, Cin, ntaps == 1 ? 1 : 9);
+}
 int use_op_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
-                 use_stream_t stream) {
+                 float* work, size_t work_floats, use_stream_t stream) {
     if (!dy || !x || !dw || B < 1 || H < 1 || W < 1 || Cout < 1 || Cin < 1 || (ntaps != 1 && ntaps != 9)) return fail(USE_E_INVALID, "use_op_wgrad: bad argument");
-    launch_wgrad(dy, x, dw, db, B, H, W, Cout, Cin, ntaps, alpha, (hipStream_t)stream);
+    if (work && work_floats < wgrad_workspace_floats(B, H, W, Cout, Cin, ntaps)) return fail(USE_E_INVALID, "use_op_wgrad: workspace too small");
+    launch_wgrad(dy, x, dw, db, B, H, W, Cout, Cin, ntaps, alpha, (work && work_floats) ? work : nullptr, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return USE_OK;
 }

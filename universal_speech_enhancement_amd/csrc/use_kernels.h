@@ -160,8 +160,10 @@ void launch_score_out(const float* pyr, int pc, const float* t, int t_stride, co
                       float2* score, int B, long pix_per_b, float sign, hipStream_t s);     // pc = 4 or 8 pyramid channels
 
 // ---- backward kernels of one res-block (use_bwd.hip; fp32 storage, NHWC): the gradient half of train_step, minimum slice ----
+// work = nullptr: the 32 x 32-tile kernel with atomic slices; else wgrad_workspace_floats() floats of scratch for the tiled kernel
+size_t wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin, int ntaps);
 void launch_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
-                  hipStream_t s);                            // dW [Cout][Cin][ntaps] (reference layout), db [Cout] or null
+                  float* work, hipStream_t s);                            // dW [Cout][Cin][ntaps] (reference layout), db [Cout] or null
 // part (fp64 scratch of gn_workspace_floats) = nullptr: the one-block-per-(item, group) forms
 void launch_gn_stats(const float* x, int B, int HW, int C, int G, float eps, float* mean, float* rstd, double* part, hipStream_t s);
 constexpr int GN_MAX_SLICES = 256;            // pixel slices per item of the sliced GroupNorm reductions (fp64 partials per slice)

@@ -67,12 +67,17 @@ def conv_dgrad(dy, w, scale=1.0):
     return conv_fwd(dy, np.ascontiguousarray(np.asarray(w).T), scale=scale, ntaps=1)
 
 
-def conv_wgrad(dy, x, ntaps=9, alpha=1.0, with_bias=True):
+def conv_wgrad(dy, x, ntaps=9, alpha=1.0, with_bias=True, tiled=True):
+    """dW [Cout][Cin][3][3] (or [Cout][Cin]) and db of y = conv(x, w) + b from dy (``use_op_wgrad``); ``tiled=False``: the small-tile
+    kernel with atomic accumulation."""
     B, H, W, Cout = dy.shape
     Cin = x.shape[3]
     dw = torch.empty(Cout, Cin, *((3, 3) if ntaps == 9 else ()), dtype=torch.float32, device=dy.device)
     db = torch.empty(Cout, dtype=torch.float32, device=dy.device) if with_bias else None
-    check(_lib.lib().use_op_wgrad(_p(dy), _p(x), _p(dw), _p(db), B, H, W, Cout, Cin, ntaps, alpha, _stream()), "use_op_wgrad")
+    lib = _lib.lib()
+    n = lib.use_op_wgrad_workspace(B, H, W, Cout, Cin, ntaps) if tiled else 0
+    work = torch.empty(n, dtype=torch.float32, device=dy.device) if n else None
+    check(lib.use_op_wgrad(_p(dy), _p(x), _p(dw), _p(db), B, H, W, Cout, Cin, ntaps, alpha, _p(work), n, _stream()), "use_op_wgrad")
     return dw, db
 
 
