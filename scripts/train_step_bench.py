@@ -12,6 +12,10 @@ from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel  # n
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 NF = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+for kv in os.environ.get("USE_OPTS", "").split(","):                      # e.g. USE_OPTS=conv_sk_max_px=4096
+    if "=" in kv:
+        from universal_speech_enhancement_amd.hip_engine import set_option
+        set_option(kv.split("=")[0], int(kv.split("=")[1]))
 torch.manual_seed(0)
 m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition="noisy", n_fft=510, hop_length=128, num_frames=NF,
                window="hann", sde_input="noisy", precision="fp32").cuda()

@@ -99,7 +99,7 @@ def test_training_forward_matches_the_sampling_engine_and_an_optimiser_step_reac
         loss = (net(x, t) - target).abs().square().mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
     with torch.no_grad():
         eng2 = net(x, t)                                                   # engine path: weights re-packed after the optimiser steps

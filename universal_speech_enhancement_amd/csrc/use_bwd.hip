@@ -582,6 +582,8 @@ void launch_attention_bwd(const float* q, const float* k, const float* v, const 
     hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(N, B), dim3(128), (size_t)(2 * N + 2 * C) * 4, s, q, k, v, dO, P, dS, dq, N, C);
     hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(N, B), dim3(128), 0, s, q, dO, P, dS, dk, dv, N, C);
 }
+static int g_wgrad_blocks = 512;      // two workgroups per CU in one round (101 vs 105 ms per training step with 1024)
+void wgrad_set_blocks(int n) { g_wgrad_blocks = n > 0 ? n : 512; }
 static WgradPlan wgrad_plan(int B, int H, int W, int Cout, int Cin) {
     WgradPlan q;
     q.CW = std::min(W, WG_PX);
@@ -590,7 +592,7 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Cout, int Cin) {
     q.chunks_x = (W + q.CW - 1) / q.CW;
     q.units = B * (H / q.RH) * q.chunks_x;
     const int tiles = ((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T);
-    int ns = std::max(1, 1024 / tiles);                               // about 4 workgroups per CU in total ...
+    int ns = std::max(1, g_wgrad_blocks / tiles);                     // about 2 workgroups per CU in total ...
     ns = std::min(ns, std::max(1, q.units / 4));                      // ... of at least 4 chunks each
     q.per_slice = (q.units + ns - 1) / ns;
     q.nslices = (q.units + q.per_slice - 1) / q.per_slice;

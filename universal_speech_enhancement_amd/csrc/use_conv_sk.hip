@@ -379,7 +379,9 @@ bool conv_sk_eligible(const ConvArgs& a) {
     // outputs: full 32-channel tiles in the input's type, or the 4- / 8-channel fp32 pyramid heads (weight rows padded to 32)
     const bool full = a.in_dtype == a.out_dtype && a.Cout % 32 == 0 && a.Cout >= 32;
     const bool head = a.out_dtype == DT_F32 && a.Cout <= 8 && a.cout_pad >= 32 && !a.pyr && !a.stats;
-    return (long)a.H * a.W <= g_sk_max_px && (a.ntaps == 9 || a.ntaps == 1) && a.w && (full || head) &&
+    // fp32 (training / parity mode): 32-channel K chunks make conv_v2's serial K loop long, split-K pays up to 64x64 maps (105 vs 114 ms per training step)
+    const long max_px = (a.in_dtype == DT_F32 && g_sk_max_px > 0) ? std::max(g_sk_max_px, 4096L) : g_sk_max_px;
+    return (long)a.H * a.W <= max_px && (a.ntaps == 9 || a.ntaps == 1) && a.w && (full || head) &&
            Ctot % 32 == 0 && a.C0 % 32 == 0 && XC % 32 == 0 && a.XC0 % 32 == 0 && (XC == 0 || a.w2) && Ctot >= 32 && Ctot <= 1024;
 }
 

@@ -917,6 +917,7 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "conv_v7_max_units")) { conv_v7_set_max_units((long)value); return USE_OK; }
     if (!strcmp(name, "conv_v7_modes")) { conv_v7_set_modes((int)value); return USE_OK; }           // bit 0: plain, 1: residual, 2: fused shortcut
     if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
+    if (!strcmp(name, "wgrad_blocks")) { wgrad_set_blocks((int)value); return USE_OK; }
     if (!strcmp(name, "conv_sk_max_px")) { conv_sk_set_max_px((long)value); return USE_OK; }             // 0: conv_sk off
 #ifdef USE_HIP_EXPERIMENTS
     if (!strcmp(name, "conv_v5_min_blocks")) { conv_v5_set_min_blocks((long)value); return USE_OK; }

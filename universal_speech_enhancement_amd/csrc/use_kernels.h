@@ -162,6 +162,7 @@ void launch_score_out(const float* pyr, int pc, const float* t, int t_stride, co
 // ---- backward kernels of one res-block (use_bwd.hip; fp32 storage, NHWC): the gradient half of train_step, minimum slice ----
 // work = nullptr: the 32 x 32-tile kernel with atomic slices; else wgrad_workspace_floats() floats of scratch for the tiled kernel
 size_t wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin, int ntaps);
+void wgrad_set_blocks(int n);                 // target workgroup count of the tiled weight-gradient kernel (tiles x pixel slices)
 void launch_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
                   float* work, hipStream_t s);                            // dW [Cout][Cin][ntaps] (reference layout), db [Cout] or null
 // part (fp64 scratch of gn_workspace_floats) = nullptr: the one-block-per-(item, group) forms
