@@ -2,9 +2,9 @@
 # training-step timing + per-kernel profile -> gpurun_out/train_*
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-python scripts/train_step_bench.py 4 256 5 > gpurun_out/train_bench.log 2>&1
+python scripts/train_step_bench.py 4 512 5 > gpurun_out/train_bench.log 2>&1
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/train_prof -o train -- python scripts/train_step_bench.py 4 256 2 > gpurun_out/train_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/train_prof -o train -- python scripts/train_step_bench.py 4 512 2 > gpurun_out/train_prof.log 2>&1
 python - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/train_prof/**/*kernel_stats.csv', recursive=True)

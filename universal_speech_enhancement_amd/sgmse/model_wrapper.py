@@ -4,7 +4,8 @@ score network and the whole reverse-SDE loop in libuse_hip.so.
 
 Additions over the reference (all optional, defaults reproduce stock behaviour): ``precision`` ("bf16" | "fp32"),
 ``use_graph``, and ``noise`` / ``seed`` keywords on ``sample`` / ``enhance`` for reproducible runs.
-Training (``train_step``) is outside this library's scope and raises.
+``train_step`` returns the loss with its tape once ``score_net.requires_grad_(True)`` was called (fp32 HIP operators forward and
+backward: ``training.py``); with frozen parameters it is the forward-only value of the sampling engine.
 """
 from __future__ import annotations
 

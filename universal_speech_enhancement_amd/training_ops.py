@@ -9,7 +9,7 @@ each other up to the gain: ``use_op_fir`` again).  fp32 storage, NHWC device ten
 * GroupNorm + SiLU backward = ``use_op_gn_act_bwd``; Dense_0 = ``use_op_colsum`` + ``use_op_dense_bwd``.
 
 The forward activations the backward needs (block input, Conv_0 output) are recomputed / taken from the forward operators by the caller;
-this module only moves pointers.  Training itself (optimiser, whole-network backward) remains outside the library.
+this module only moves pointers.  The whole-network tape built on these operators is ``training.py``.
 """
 from __future__ import annotations
 
