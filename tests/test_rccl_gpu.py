@@ -65,3 +65,36 @@ def test_bench_under_the_launcher_with_one_process():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["parallelism"] == "utterance-sharded x1"
+
+
+_TRAIN_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["USE_ROOT"])
+import torch, torch.distributed as dist
+from universal_speech_enhancement_amd import distributed as D
+from universal_speech_enhancement_amd.sgmse.backbones import BackboneRegistry
+from universal_speech_enhancement_amd.testing import noise as tn
+rank, world, local = D.init_from_env()
+assert dist.get_backend() == "nccl" and world == 1
+torch.manual_seed(3)
+net = BackboneRegistry.get_by_name("ncsnpp6M")(input_channels=4, precision="fp32", init_scale=1.0).cuda()
+net.requires_grad_(True)
+x = torch.from_numpy(tn.complex_normal(5, "trn_x", (2, 2, 64, 64))).cuda() * 0.5
+lo, hi = D.shard_bounds(x.shape[0], rank, world)                     # each rank's share of the batch
+loss = net(x[lo:hi], torch.tensor([0.4, 0.9], device="cuda")[lo:hi]).abs().square().mean()
+loss.backward()
+before = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+n = D.allreduce_gradients(net.parameters())                          # 6 M fp32 gradients: one RCCL all-reduce
+torch.cuda.synchronize()
+assert n == 1 and len(before) > 100
+assert all(torch.equal(before[k], p.grad) for k, p in net.named_parameters() if k in before)   # mean over one rank = identity
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_TRAIN_WORLD1_OK")
+"""
+
+
+def test_gradient_allreduce_over_rccl_at_world_size_one():
+    """The data-parallel training exchange (distributed.allreduce_gradients) on the RCCL backend: gradients of a taped forward +
+    backward, packed into one bucket, all-reduced on the GPU and handed back unchanged at world size 1."""
+    r = subprocess.run([sys.executable, "-c", _TRAIN_WORKER], env=_env(_free_port()), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RCCL_TRAIN_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
