@@ -218,7 +218,9 @@ int use_op_attention(const void* q, const void* k, const void* v, void* out, int
 int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta, int groups,
                        int hw, float eps, float* coef, int B, use_stream_t stream);
 /* ---- backward operators of one res-block (minimum slice of ScoreModel.train_step's gradients, reference
- * model_wrapper.py:147-208 / SGMSE_module.py:46-54).  fp32 NHWC device tensors.  The data gradient of a convolution is use_op_conv
+ * model_wrapper.py:147-208 / SGMSE_module.py:46-54).  NHWC device tensors; activations and their gradients in `dtype` (0 fp32 /
+ * 1 bf16 / 2 fp16 storage: mixed-precision training keeps fp32 parameters, statistics and parameter gradients) where a dtype
+ * argument is present, fp32 elsewhere.  The data gradient of a convolution is use_op_conv
  * itself on the flipped, transposed weights; these are the rest:
  * use_op_wgrad:      dW[co][ci][tap] = alpha * sum dY[b,p,co] X[b,p+tap,ci] (reference weight layout), db[co] = alpha * sum dY (or null).
  *                    work: use_op_wgrad_workspace(...) floats of scratch for the tiled kernel (per-slice partial tiles, summed without
@@ -230,13 +232,13 @@ int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C
  * use_op_dense_bwd:  Dense_0(SiLU(temb)): g [B][Cout] -> dW [Cout][K], db [Cout], dtemb [B][K].
  * use_op_attention_bwd: the AttnBlockpp core, out = softmax(q k^T / sqrt(C)) v: dq, dk, dv from dO ([B][N][C] each; work: 2 B N N floats). */
 size_t use_op_wgrad_workspace(int B, int H, int W, int Cout, int Cin, int ntaps);
-int use_op_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
+int use_op_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
                  float* work, size_t work_floats, use_stream_t stream);
 size_t use_op_gn_workspace(int B, int C, int groups);
-int use_op_gn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, int groups, float eps, int act, const float* add,
-                      float add_scale, int B, int HW, int C, float* work, float* dx, float* dgamma, float* dbeta, use_stream_t stream);
-int use_op_gn_act_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, int act, int B, int HW, int C, float* work,
-                      float* y, use_stream_t stream);
+int use_op_gn_act_bwd(const void* x, const void* dy, int dtype, const float* gamma, const float* beta, int groups, float eps, int act, const void* add,
+                      float add_scale, int B, int HW, int C, float* work, void* dx, float* dgamma, float* dbeta, use_stream_t stream);
+int use_op_gn_act_fwd(const void* x, int dtype, const float* gamma, const float* beta, int groups, float eps, int act, int B, int HW, int C, float* work,
+                      void* y, use_stream_t stream);
 int use_op_colsum(const float* x, int B, int HW, int C, float scale, float* out, use_stream_t stream);
 int use_op_dense_bwd(const float* g, const float* temb, const float* Wd, int B, int K, int Cout, float* dW, float* db, float* dtemb,
                      use_stream_t stream);

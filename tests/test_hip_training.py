@@ -75,6 +75,40 @@ def test_training_step_gradients_match_the_reference_backward(golden_dir, tag):
     print(f"[measured] train grads {tag}: worst norm rel {worst_n:.3g}, worst tensor rel-to-max {worst_t:.3g}, {n_checked} tensors")
 
 
+@pytest.mark.parametrize("prec,tol_loss,tol_norm,tol_tensor", [("bf16", 2.2e-3, 4.3e-2, 0.25), ("fp16", 5e-5, 1.6e-3, 2.1e-2)])
+def test_mixed_precision_gradients_stay_close_to_the_fp32_reference(golden_dir, prec, tol_loss, tol_norm, tol_tensor):
+    """score_net.train_precision = "bf16" / "fp16": activations and their gradients in 16 bits, convolutions on the 16-bit MFMA kernels,
+    parameters / weight gradients / statistics fp32 - against the reference's fp32 backward (case a).  Bounds about 2x the measured
+    deviations (printed): bf16 loss 1.1e-3, gradient norms 2.1e-2, worst stored tensor 0.12 of its maximum (rms over all stored entries
+    7.8e-3); fp16 2.3e-5 / 7.8e-4 / 1.0e-2 (no loss scaling: the gradients of this loss sit well inside fp16's range)."""
+    m, batch, t, z, start, g = _case(golden_dir, "a")
+    m.score_net.requires_grad_(True)
+    m.score_net.train_precision = prec
+    loss = m.train_step(batch, t=t, z=z, start=start)
+    want = float(g["loss"])
+    e_loss = abs(float(loss.detach()) - want) / want
+    loss.backward()
+    torch.cuda.synchronize()
+    P = dict(m.score_net.named_parameters())
+    worst_n, worst_t, tot_num, tot_den = 0.0, 0.0, 0.0, 0.0
+    for key in g.files:
+        kind, _, name = key.partition(".")
+        if kind not in ("n", "g", "c") or name.endswith("NIN_1.b"):
+            continue
+        got = P[name].grad
+        assert got is not None and got.dtype == torch.float32 and torch.isfinite(got).all(), name
+        if kind == "n":
+            worst_n = max(worst_n, abs(float(got.double().norm()) - float(g[key])) / float(g[key]))
+        else:
+            ref = torch.from_numpy(g[key])
+            have = got.detach().cpu() if kind == "g" else got.detach()[:4, :4].cpu()
+            worst_t = max(worst_t, float((have - ref).abs().max()) / float(ref.abs().max()))
+            tot_num += float((have - ref).double().square().sum()); tot_den += float(ref.double().square().sum())
+    print(f"[measured] mixed {prec}: loss rel {e_loss:.3g}, worst norm rel {worst_n:.3g}, worst tensor rel-to-max {worst_t:.3g}, "
+          f"stored entries rms rel {np.sqrt(tot_num / tot_den):.3g}")
+    assert e_loss < tol_loss and worst_n < tol_norm and worst_t < tol_tensor
+
+
 def test_training_forward_matches_the_sampling_engine_and_an_optimiser_step_reaches_it():
     """The taped forward (training.ncsnpp_forward_train) and the sampling engine's fp32 forward are the same network: same output to
     1e-4 on a small configuration; after optimiser steps the loss on the fixed batch goes down and the engine (re-packed from the updated

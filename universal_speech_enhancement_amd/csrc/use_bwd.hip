@@ -84,8 +84,21 @@ constexpr int WG_SMEM = (WG_PX * WG_T + WG_PATCH * WG_T) * 4 + WG_PX * 4;
 
 struct WgradPlan { int RH, CW, chunks_x, units, per_slice, nslices; };
 
-template <int NT>
-__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+template <typename T> DEVI void wg_ld4(const T* p, float (&v)[4]);                       // 4 consecutive channels -> fp32
+template <> DEVI void wg_ld4<float>(const float* p, float (&v)[4]) { const float4 u = *reinterpret_cast<const float4*>(p); v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; }
+template <> DEVI void wg_ld4<__bf16>(const __bf16* p, float (&v)[4]) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    v[0] = __builtin_bit_cast(float, u.x << 16); v[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, u.y << 16); v[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+}
+template <> DEVI void wg_ld4<_Float16>(const _Float16* p, float (&v)[4]) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 u = *reinterpret_cast<const h4*>(p);
+    v[0] = (float)u[0]; v[1] = (float)u[1]; v[2] = (float)u[2]; v[3] = (float)u[3];
+}
+
+template <int NT, typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ part,
                                                             float* __restrict__ bpart, int B, int H, int W, int Cout, int Cin, WgradPlan q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* dyS = reinterpret_cast<float*>(smem);                        // [64 px][64 co]
@@ -111,29 +124,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const float* __restr
         __syncthreads();                                                // the previous chunk's MFMAs are done with the LDS
         for (int e = t; e < WG_PX * (WG_T / 4); e += 256) {             // dY chunk
             const int j = e / (WG_T / 4), c4 = (e % (WG_T / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
             const int r = j / q.CW, cxx = x0 + j % q.CW;
-            if (j < nchunk && cxx < W && co0 + c4 < Cout)
-                v = *reinterpret_cast<const float4*>(dy + (((size_t)b * H + y0 + r) * W + cxx) * Cout + co0 + c4);
-            *reinterpret_cast<float4*>(dyS + j * WG_T + c4) = v;
+            if (j < nchunk && cxx < W && co0 + c4 < Cout) wg_ld4<T>(dy + (((size_t)b * H + y0 + r) * W + cxx) * Cout + co0 + c4, v);
+            *reinterpret_cast<float4*>(dyS + j * WG_T + c4) = make_float4(v[0], v[1], v[2], v[3]);
         }
         if (NT == 9) {
             for (int e = t; e < npatch * (WG_T / 4); e += 256) {        // X patch with a one-pixel halo, zero outside the image
                 const int pp = e / (WG_T / 4), c4 = (e % (WG_T / 4)) * 4;
                 const int yy = y0 + pp / PWp - 1, xx = x0 + pp % PWp - 1;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W && ci0 + c4 < Cin)
-                    v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + yy) * W + xx) * Cin + ci0 + c4);
-                *reinterpret_cast<float4*>(xS + pp * WG_T + c4) = v;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W && ci0 + c4 < Cin) wg_ld4<T>(x + (((size_t)b * H + yy) * W + xx) * Cin + ci0 + c4, v);
+                *reinterpret_cast<float4*>(xS + pp * WG_T + c4) = make_float4(v[0], v[1], v[2], v[3]);
             }
         } else {
             for (int e = t; e < WG_PX * (WG_T / 4); e += 256) {         // 1x1: the chunk's own pixels, stored at their patch positions
                 const int j = e / (WG_T / 4), c4 = (e % (WG_T / 4)) * 4;
                 const int r = j / q.CW, cxx = x0 + j % q.CW;
                 if (j < nchunk) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (cxx < W && ci0 + c4 < Cin) v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + y0 + r) * W + cxx) * Cin + ci0 + c4);
-                    *reinterpret_cast<float4*>(xS + ((r + 1) * PWp + j % q.CW + 1) * WG_T + c4) = v;
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (cxx < W && ci0 + c4 < Cin) wg_ld4<T>(x + (((size_t)b * H + y0 + r) * W + cxx) * Cin + ci0 + c4, v);
+                    *reinterpret_cast<float4*>(xS + ((r + 1) * PWp + j % q.CW + 1) * WG_T + c4) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
@@ -280,29 +291,34 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const float* __restrict
 // pixel (16-byte loads along the channels), folds its pixel lanes through LDS and leaves one fp64 partial per (slice, channel | group);
 // a one-block-per-item kernel sums the slices.  These replace the one-block-per-(item, group | 64 channels) kernels above, which leave
 // the chip idle on the full-resolution maps (8 blocks for a 128-channel map of 4 items).
-__host__ __device__ inline int gn_slices(int HW, int C) {
-    const int ppi = 256 / (C / 4);
+__host__ __device__ inline int gn_slices(int HW, int C, int vec) {
+    const int ppi = 256 / (C / vec);
     int n = HW / (ppi * 8);
     return n < 1 ? 1 : n > GN_MAX_SLICES ? GN_MAX_SLICES : n;
 }
 
-__global__ __launch_bounds__(256) void gn_stats_part_kernel(const float* __restrict__ x, int HW, int C, int G, double* __restrict__ part) {
-    __shared__ float sh[2][1024];
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_part_kernel(const T* __restrict__ x, int HW, int C, int G, double* __restrict__ part) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float sh[2][256 * VEC];
     __shared__ double ch[2][1024];
-    const int tpp = C / 4, ppi = 256 / tpp, t = threadIdx.x, b = blockIdx.y, ns = gridDim.x;
+    const int tpp = C / VEC, ppi = 256 / tpp, t = threadIdx.x, b = blockIdx.y, ns = gridDim.x;
     const int per = (HW + ns - 1) / ns, lo = blockIdx.x * per, hi = lo + per < HW ? lo + per : HW;
     const bool on = t < tpp * ppi;
-    const int pl = t / tpp, c4 = (t % tpp) * 4;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    const int pl = t / tpp, c4 = (t % tpp) * VEC;
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { s[k] = 0.f; q[k] = 0.f; }
     if (on)
         for (int p = lo + pl; p < hi; p += ppi) {
-            const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * HW + p) * C + c4);
-            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-            q[0] = fmaf(v.x, v.x, q[0]); q[1] = fmaf(v.y, v.y, q[1]); q[2] = fmaf(v.z, v.z, q[2]); q[3] = fmaf(v.w, v.w, q[3]);
+            float v[VEC];
+            Vec16<T>::load(x + ((size_t)b * HW + p) * C + c4, v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { s[k] += v[k]; q[k] = fmaf(v[k], v[k], q[k]); }
         }
     if (on) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { sh[0][pl * C + c4 + k] = s[k]; sh[1][pl * C + c4 + k] = q[k]; }
+        for (int k = 0; k < VEC; ++k) { sh[0][pl * C + c4 + k] = s[k]; sh[1][pl * C + c4 + k] = q[k]; }
     }
     __syncthreads();
     for (int c = t; c < C; c += 256) {
@@ -334,36 +350,37 @@ __global__ __launch_bounds__(64) void gn_stats_fin_kernel(const double* __restri
     }
 }
 
-template <bool ACT>
-__global__ __launch_bounds__(256) void gn_act_bwd_part_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+template <typename T, bool ACT>
+__global__ __launch_bounds__(256) void gn_act_bwd_part_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int HW, int C, int G, double* __restrict__ part) {
-    __shared__ float sh[2][1024];
-    const int tpp = C / 4, ppi = 256 / tpp, t = threadIdx.x, b = blockIdx.y, ns = gridDim.x, cpg = C / G;
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float sh[2][256 * VEC];
+    const int tpp = C / VEC, ppi = 256 / tpp, t = threadIdx.x, b = blockIdx.y, ns = gridDim.x, cpg = C / G;
     const int per = (HW + ns - 1) / ns, lo = blockIdx.x * per, hi = lo + per < HW ? lo + per : HW;
     const bool on = t < tpp * ppi;
-    const int pl = t / tpp, c4 = (t % tpp) * 4;
-    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int pl = t / tpp, c4 = (t % tpp) * VEC;
     if (on) {
-        float mu[4], rs[4], gm[4], bt[4];
+        float a1[VEC], a2[VEC], mu[VEC], rs[VEC], gm[VEC], bt[VEC];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < VEC; ++k) {
             const int g = (c4 + k) / cpg;
+            a1[k] = 0.f; a2[k] = 0.f;
             mu[k] = mean[b * G + g]; rs[k] = rstd[b * G + g]; gm[k] = gamma[c4 + k]; bt[k] = beta[c4 + k];
         }
         for (int p = lo + pl; p < hi; p += ppi) {
             const size_t i = ((size_t)b * HW + p) * C + c4;
-            const float4 xv = *reinterpret_cast<const float4*>(x + i), dv = *reinterpret_cast<const float4*>(dy + i);
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+            float xs[VEC], ds[VEC];
+            Vec16<T>::load(x + i, xs); Vec16<T>::load(dy + i, ds);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < VEC; ++k) {
                 const float xh = (xs[k] - mu[k]) * rs[k];
                 const float du = ds[k] * act_grad<ACT>(fmaf(gm[k], xh, bt[k]));
                 a1[k] += du; a2[k] = fmaf(du, xh, a2[k]);
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { sh[0][pl * C + c4 + k] = a1[k]; sh[1][pl * C + c4 + k] = a2[k]; }
+        for (int k = 0; k < VEC; ++k) { sh[0][pl * C + c4 + k] = a1[k]; sh[1][pl * C + c4 + k] = a2[k]; }
     }
     __syncthreads();
     for (int c = t; c < C; c += 256) {
@@ -392,48 +409,48 @@ __global__ __launch_bounds__(64) void gn_act_bwd_fin_kernel(const double* __rest
         m1[blockIdx.x] = (float)(ga * inv); m2[blockIdx.x] = (float)(ge * inv);
     }
 }
-template <bool ACT>
-__global__ __launch_bounds__(256) void gn_act_bwd_apply4_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+template <typename T, bool ACT>
+__global__ __launch_bounds__(256) void gn_act_bwd_applyv_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, const float* __restrict__ m1,
-                                                                const float* __restrict__ m2, const float* __restrict__ add, float add_scale, int HW,
-                                                                int C, int G, float* __restrict__ dx, long n4) {
-    const int cpg = C / G, c4n = C / 4;
-    for (long i4 = (long)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * 256) {
-        const int c4 = (int)(i4 % c4n) * 4, b = (int)(i4 / ((long)HW * c4n));
-        const size_t i = (size_t)i4 * 4;
-        const float4 xv = *reinterpret_cast<const float4*>(x + i), dv = *reinterpret_cast<const float4*>(dy + i);
-        float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (add) av = *reinterpret_cast<const float4*>(add + i);
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w}, as[4] = {av.x, av.y, av.z, av.w};
-        float o[4];
+                                                                const float* __restrict__ m2, const T* __restrict__ add, float add_scale, int HW,
+                                                                int C, int G, T* __restrict__ dx, long nv) {
+    constexpr int VEC = Vec16<T>::N;
+    const int cpg = C / G, cvn = C / VEC;
+    for (long iv = (long)blockIdx.x * 256 + threadIdx.x; iv < nv; iv += (long)gridDim.x * 256) {
+        const int c4 = (int)(iv % cvn) * VEC, b = (int)(iv / ((long)HW * cvn));
+        const size_t i = (size_t)iv * VEC;
+        float xs[VEC], ds[VEC], as[VEC], o[VEC];
+        Vec16<T>::load(x + i, xs); Vec16<T>::load(dy + i, ds);
+        if (add) Vec16<T>::load(add + i, as);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < VEC; ++k) {
             const int c = c4 + k, g = c / cpg;
             const float rs = rstd[b * G + g], xh = (xs[k] - mean[b * G + g]) * rs, gm = gamma[c];
             const float du = ds[k] * act_grad<ACT>(fmaf(gm, xh, beta[c]));
-            o[k] = fmaf(add_scale, as[k], rs * (gm * du - m1[b * G + g] - xh * m2[b * G + g]));
+            o[k] = rs * (gm * du - m1[b * G + g] - xh * m2[b * G + g]);
+            if (add) o[k] = fmaf(add_scale, as[k], o[k]);
         }
-        *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
+        Vec16<T>::store(dx + i, o);
     }
 }
-template <bool ACT>
-__global__ __launch_bounds__(256) void gn_act_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+template <typename T, bool ACT>
+__global__ __launch_bounds__(256) void gn_act_fwdv_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C, int G,
-                                                          float* __restrict__ y, long n4) {
-    const int cpg = C / G, c4n = C / 4;
-    for (long i4 = (long)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * 256) {
-        const int c4 = (int)(i4 % c4n) * 4, b = (int)(i4 / ((long)HW * c4n));
-        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)i4 * 4);
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        float o[4];
+                                                          T* __restrict__ y, long nv) {
+    constexpr int VEC = Vec16<T>::N;
+    const int cpg = C / G, cvn = C / VEC;
+    for (long iv = (long)blockIdx.x * 256 + threadIdx.x; iv < nv; iv += (long)gridDim.x * 256) {
+        const int c4 = (int)(iv % cvn) * VEC, b = (int)(iv / ((long)HW * cvn));
+        float xs[VEC], o[VEC];
+        Vec16<T>::load(x + (size_t)iv * VEC, xs);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < VEC; ++k) {
             const int c = c4 + k, g = c / cpg;
             const float u = fmaf(gamma[c], (xs[k] - mean[b * G + g]) * rstd[b * G + g], beta[c]);
             o[k] = ACT ? u / (1.0f + expf(-u)) : u;
         }
-        *reinterpret_cast<float4*>(y + (size_t)i4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        Vec16<T>::store(y + (size_t)iv * VEC, o);
     }
 }
 
@@ -603,87 +620,133 @@ size_t wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin, int ntaps)
     const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin);
     return (size_t)q.nslices * ((size_t)Cout * Cin * ntaps + Cout);
 }
-void launch_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
+template <typename T>
+static void wgrad_tile_t(const void* dy, const void* x, float* part, float* bpart, int B, int H, int W, int Cout, int Cin, int ntaps, const WgradPlan& q,
+                         hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel<9, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel<1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
+        attr = true;
+    }
+    const dim3 grid(((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T), q.nslices);
+    if (ntaps == 9) hipLaunchKernelGGL((wgrad_tile_kernel<9, T>), grid, dim3(256), WG_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
+    else            hipLaunchKernelGGL((wgrad_tile_kernel<1, T>), grid, dim3(256), WG_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
+}
+// dy / x in `dtype` (converted to fp32 while staging: the contraction is exact-fp32 MFMA either way); dw / db fp32.  16-bit inputs need the
+// tiled kernel (work != nullptr, channel counts multiples of 4): returns false otherwise.
+bool launch_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
                   float* work, hipStream_t s) {
     if (work && Cout % 4 == 0 && Cin % 4 == 0) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
-            attr = true;
-        }
         const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin);
         const long n = (long)Cout * Cin * ntaps;
         float* part = work; float* bpart = work + (size_t)q.nslices * n;
-        const dim3 grid(((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T), q.nslices);
-        if (ntaps == 9) hipLaunchKernelGGL(wgrad_tile_kernel<9>, grid, dim3(256), WG_SMEM, s, dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, q);
-        else            hipLaunchKernelGGL(wgrad_tile_kernel<1>, grid, dim3(256), WG_SMEM, s, dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, q);
+        if (dtype == DT_F32) wgrad_tile_t<float>(dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, ntaps, q, s);
+        else if (dtype == DT_BF16) wgrad_tile_t<__bf16>(dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, ntaps, q, s);
+        else wgrad_tile_t<_Float16>(dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, ntaps, q, s);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, s, part, q.nslices, n, alpha, dw);
         if (db) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, bpart, q.nslices, (long)Cout, alpha, db);
-        return;
+        return true;
     }
+    if (dtype != DT_F32) return false;
     const long npix = (long)B * H * W;
     int nslices = (int)std::min<long>(64, std::max<long>(1, npix / 4096));     // pixel slices (atomic accumulation when > 1)
     if (nslices > 1) {
         (void)hipMemsetAsync(dw, 0, (size_t)Cout * Cin * ntaps * 4, s);
         if (db) (void)hipMemsetAsync(db, 0, (size_t)Cout * 4, s);
     }
-    hipLaunchKernelGGL(wgrad_kernel, dim3((Cout + 31) / 32, (Cin + 31) / 32, ntaps * nslices), dim3(256), 0, s, dy, x, dw, db, B, H, W, Cout, Cin,
-                       ntaps, nslices, alpha);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((Cout + 31) / 32, (Cin + 31) / 32, ntaps * nslices), dim3(256), 0, s, (const float*)dy, (const float*)x, dw, db, B,
+                       H, W, Cout, Cin, ntaps, nslices, alpha);
+    return true;
 }
-static bool gn_sliced(int C, int G) { return C % 4 == 0 && C <= 1024 && G <= 1024; }
+static int vec_of(int dtype) { return dtype == DT_F32 ? 4 : 8; }
+static bool gn_sliced(int C, int G, int dtype) { const int v = vec_of(dtype); return C % v == 0 && C / v <= 256 && C <= 1024 && G <= 1024; }
 size_t gn_workspace_floats(int B, int C, int G) {
     // [fp64 partials: 2 B slices max(C, G)] [mean, rstd: 2 B G] [s1, s2: 2 B C] [m1, m2: 2 B G]
     return (size_t)4 * B * GN_MAX_SLICES * std::max(C, G) + (size_t)4 * B * G + (size_t)2 * B * C;
 }
-void launch_gn_stats(const float* x, int B, int HW, int C, int G, float eps, float* mean, float* rstd, double* part, hipStream_t s) {
-    if (part && gn_sliced(C, G)) {
-        const int ns = gn_slices(HW, C);
-        hipLaunchKernelGGL(gn_stats_part_kernel, dim3(ns, B), dim3(256), 0, s, x, HW, C, G, part);
-        hipLaunchKernelGGL(gn_stats_fin_kernel, dim3(B * G), dim3(64), 0, s, part, ns, G, (double)HW * (C / G), eps, mean, rstd);
-        return;
-    }
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * G), dim3(256), 0, s, x, HW, C, G, eps, mean, rstd);
+// x / dy / y / dx in `dtype` (fp32, bf16, fp16 storage); statistics, affine parameters and their gradients fp32.  The 16-bit types need
+// the sliced kernels (part != nullptr, C a multiple of 8): returns false when the case cannot be served.
+template <typename T>
+static void gn_stats_t(const void* x, int B, int HW, int C, int G, float eps, float* mean, float* rstd, double* part, hipStream_t s) {
+    const int ns = gn_slices(HW, C, Vec16<T>::N);
+    hipLaunchKernelGGL(gn_stats_part_kernel<T>, dim3(ns, B), dim3(256), 0, s, (const T*)x, HW, C, G, part);
+    hipLaunchKernelGGL(gn_stats_fin_kernel, dim3(B * G), dim3(64), 0, s, part, ns, G, (double)HW * (C / G), eps, mean, rstd);
 }
-void launch_gn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
-                       const float* add, float add_scale, int B, int HW, int C, int G, float* s1, float* s2, float* m12, double* part, float* dx,
+bool launch_gn_stats(const void* x, int dtype, int B, int HW, int C, int G, float eps, float* mean, float* rstd, double* part, hipStream_t s) {
+    if (part && gn_sliced(C, G, dtype)) {
+        if (dtype == DT_F32) gn_stats_t<float>(x, B, HW, C, G, eps, mean, rstd, part, s);
+        else if (dtype == DT_BF16) gn_stats_t<__bf16>(x, B, HW, C, G, eps, mean, rstd, part, s);
+        else gn_stats_t<_Float16>(x, B, HW, C, G, eps, mean, rstd, part, s);
+        return true;
+    }
+    if (dtype != DT_F32) return false;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * G), dim3(256), 0, s, (const float*)x, HW, C, G, eps, mean, rstd);
+    return true;
+}
+template <typename T>
+static void gn_act_bwd_t(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                         const void* add, float add_scale, int B, int HW, int C, int G, float* s1, float* s2, float* m12, double* part, void* dx,
+                         hipStream_t s) {
+    constexpr int VEC = Vec16<T>::N;
+    const long n = (long)B * HW * C;
+    const int ns = gn_slices(HW, C, VEC);
+    float* m1 = m12; float* m2 = m12 + (size_t)B * G;
+    const unsigned blocks = (unsigned)std::min<long>((n / VEC + 255) / 256, 8192);
+    if (act) hipLaunchKernelGGL((gn_act_bwd_part_kernel<T, true>), dim3(ns, B), dim3(256), 0, s, (const T*)x, (const T*)dy, mean, rstd, gamma, beta, HW, C, G, part);
+    else     hipLaunchKernelGGL((gn_act_bwd_part_kernel<T, false>), dim3(ns, B), dim3(256), 0, s, (const T*)x, (const T*)dy, mean, rstd, gamma, beta, HW, C, G, part);
+    hipLaunchKernelGGL(gn_act_bwd_fin_kernel, dim3(B * G), dim3(64), 0, s, part, gamma, ns, HW, C, G, s1, s2, m1, m2);
+    if (act) hipLaunchKernelGGL((gn_act_bwd_applyv_kernel<T, true>), dim3(blocks), dim3(256), 0, s, (const T*)x, (const T*)dy, mean, rstd, gamma, beta, m1, m2, (const T*)add, add_scale, HW, C, G, (T*)dx, n / VEC);
+    else     hipLaunchKernelGGL((gn_act_bwd_applyv_kernel<T, false>), dim3(blocks), dim3(256), 0, s, (const T*)x, (const T*)dy, mean, rstd, gamma, beta, m1, m2, (const T*)add, add_scale, HW, C, G, (T*)dx, n / VEC);
+}
+bool launch_gn_act_bwd(const void* x, const void* dy, int dtype, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                       const void* add, float add_scale, int B, int HW, int C, int G, float* s1, float* s2, float* m12, double* part, void* dx,
                        float* dgamma, float* dbeta, hipStream_t s) {
     const long n = (long)B * HW * C;
-    if (part && m12 && gn_sliced(C, G)) {
-        const int ns = gn_slices(HW, C);
-        float* m1 = m12; float* m2 = m12 + (size_t)B * G;
-        const unsigned blocks = (unsigned)std::min<long>((n / 4 + 255) / 256, 8192);
-        if (act) hipLaunchKernelGGL(gn_act_bwd_part_kernel<true>, dim3(ns, B), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, part);
-        else     hipLaunchKernelGGL(gn_act_bwd_part_kernel<false>, dim3(ns, B), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, part);
-        hipLaunchKernelGGL(gn_act_bwd_fin_kernel, dim3(B * G), dim3(64), 0, s, part, gamma, ns, HW, C, G, s1, s2, m1, m2);
-        if (act) hipLaunchKernelGGL(gn_act_bwd_apply4_kernel<true>, dim3(blocks), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, m1, m2, add, add_scale, HW, C, G, dx, n / 4);
-        else     hipLaunchKernelGGL(gn_act_bwd_apply4_kernel<false>, dim3(blocks), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, m1, m2, add, add_scale, HW, C, G, dx, n / 4);
+    if (part && m12 && gn_sliced(C, G, dtype)) {
+        if (dtype == DT_F32) gn_act_bwd_t<float>(x, dy, mean, rstd, gamma, beta, act, add, add_scale, B, HW, C, G, s1, s2, m12, part, dx, s);
+        else if (dtype == DT_BF16) gn_act_bwd_t<__bf16>(x, dy, mean, rstd, gamma, beta, act, add, add_scale, B, HW, C, G, s1, s2, m12, part, dx, s);
+        else gn_act_bwd_t<_Float16>(x, dy, mean, rstd, gamma, beta, act, add, add_scale, B, HW, C, G, s1, s2, m12, part, dx, s);
         hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 127) / 128), dim3(128), 0, s, s1, s2, B, C, dgamma, dbeta);
-        return;
+        return true;
     }
+    if (dtype != DT_F32) return false;
+    const float* xf = (const float*)x; const float* dyf = (const float*)dy; const float* addf = (const float*)add; float* dxf = (float*)dx;
     const dim3 gr((C + 63) / 64, B);
     const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 4096);
     if (act) {
-        hipLaunchKernelGGL(gn_act_bwd_reduce<true>, gr, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, s1, s2);
-        hipLaunchKernelGGL(gn_act_bwd_apply<true>, dim3(blocks), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, s1, s2, add, add_scale, HW, C, G, dx, n);
+        hipLaunchKernelGGL(gn_act_bwd_reduce<true>, gr, dim3(256), 0, s, xf, dyf, mean, rstd, gamma, beta, HW, C, G, s1, s2);
+        hipLaunchKernelGGL(gn_act_bwd_apply<true>, dim3(blocks), dim3(256), 0, s, xf, dyf, mean, rstd, gamma, beta, s1, s2, addf, add_scale, HW, C, G, dxf, n);
     } else {
-        hipLaunchKernelGGL(gn_act_bwd_reduce<false>, gr, dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, HW, C, G, s1, s2);
-        hipLaunchKernelGGL(gn_act_bwd_apply<false>, dim3(blocks), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, s1, s2, add, add_scale, HW, C, G, dx, n);
+        hipLaunchKernelGGL(gn_act_bwd_reduce<false>, gr, dim3(256), 0, s, xf, dyf, mean, rstd, gamma, beta, HW, C, G, s1, s2);
+        hipLaunchKernelGGL(gn_act_bwd_apply<false>, dim3(blocks), dim3(256), 0, s, xf, dyf, mean, rstd, gamma, beta, s1, s2, addf, add_scale, HW, C, G, dxf, n);
     }
     hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 127) / 128), dim3(128), 0, s, s1, s2, B, C, dgamma, dbeta);
+    return true;
 }
-void launch_gn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int B, int HW, int C,
-                       int G, float* y, hipStream_t s) {
+template <typename T>
+static void gn_act_fwd_t(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int B, int HW, int C,
+                         int G, void* y, hipStream_t s) {
+    constexpr int VEC = Vec16<T>::N;
     const long n = (long)B * HW * C;
-    if (C % 4 == 0) {
-        const unsigned blocks = (unsigned)std::min<long>((n / 4 + 255) / 256, 8192);
-        if (act) hipLaunchKernelGGL(gn_act_fwd4_kernel<true>, dim3(blocks), dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y, n / 4);
-        else     hipLaunchKernelGGL(gn_act_fwd4_kernel<false>, dim3(blocks), dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y, n / 4);
-        return;
+    const unsigned blocks = (unsigned)std::min<long>((n / VEC + 255) / 256, 8192);
+    if (act) hipLaunchKernelGGL((gn_act_fwdv_kernel<T, true>), dim3(blocks), dim3(256), 0, s, (const T*)x, mean, rstd, gamma, beta, HW, C, G, (T*)y, n / VEC);
+    else     hipLaunchKernelGGL((gn_act_fwdv_kernel<T, false>), dim3(blocks), dim3(256), 0, s, (const T*)x, mean, rstd, gamma, beta, HW, C, G, (T*)y, n / VEC);
+}
+bool launch_gn_act_fwd(const void* x, int dtype, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int B, int HW,
+                       int C, int G, void* y, hipStream_t s) {
+    const long n = (long)B * HW * C;
+    if (C % vec_of(dtype) == 0) {
+        if (dtype == DT_F32) gn_act_fwd_t<float>(x, mean, rstd, gamma, beta, act, B, HW, C, G, y, s);
+        else if (dtype == DT_BF16) gn_act_fwd_t<__bf16>(x, mean, rstd, gamma, beta, act, B, HW, C, G, y, s);
+        else gn_act_fwd_t<_Float16>(x, mean, rstd, gamma, beta, act, B, HW, C, G, y, s);
+        return true;
     }
+    if (dtype != DT_F32) return false;
     const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 4096);
-    if (act) hipLaunchKernelGGL(gn_act_fwd_kernel<true>, dim3(blocks), dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y, n);
-    else     hipLaunchKernelGGL(gn_act_fwd_kernel<false>, dim3(blocks), dim3(256), 0, s, x, mean, rstd, gamma, beta, HW, C, G, y, n);
+    if (act) hipLaunchKernelGGL(gn_act_fwd_kernel<true>, dim3(blocks), dim3(256), 0, s, (const float*)x, mean, rstd, gamma, beta, HW, C, G, (float*)y, n);
+    else     hipLaunchKernelGGL(gn_act_fwd_kernel<false>, dim3(blocks), dim3(256), 0, s, (const float*)x, mean, rstd, gamma, beta, HW, C, G, (float*)y, n);
+    return true;
 }
 void launch_colsum(const float* x, int B, int HW, int C, float scale, float* out, hipStream_t s) {
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, x, HW, C, scale, out);

@@ -1796,38 +1796,44 @@ int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C
 size_t use_op_wgrad_workspace(int B, int H, int W, int Cout, int Cin, int ntaps) {
     return (B < 1 || H < 1 || W < 1 || Cout < 1 || Cin < 1) ? 0 : wgrad_workspace_floats(B, H, W, Cout, Cin, ntaps == 1 ? 1 : 9);
 }
-int use_op_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
+int use_op_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
                  float* work, size_t work_floats, use_stream_t stream) {
     if (!dy || !x || !dw || B < 1 || H < 1 || W < 1 || Cout < 1 || Cin < 1 || (ntaps != 1 && ntaps != 9)) return fail(USE_E_INVALID, "use_op_wgrad: bad argument");
+    if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_F16) return fail(USE_E_INVALID, "use_op_wgrad: bad dtype");
     if (work && work_floats < wgrad_workspace_floats(B, H, W, Cout, Cin, ntaps)) return fail(USE_E_INVALID, "use_op_wgrad: workspace too small");
-    launch_wgrad(dy, x, dw, db, B, H, W, Cout, Cin, ntaps, alpha, (work && work_floats) ? work : nullptr, (hipStream_t)stream);
+    if (!launch_wgrad(dy, x, dtype, dw, db, B, H, W, Cout, Cin, ntaps, alpha, (work && work_floats) ? work : nullptr, (hipStream_t)stream))
+        return fail(USE_E_INVALID, "use_op_wgrad: 16-bit inputs need the workspace and channel counts that are multiples of 4");
     HIPCHK(hipGetLastError());
     return USE_OK;
 }
 // workspace of the two GroupNorm operators, in floats (8-byte aligned): [fp64 slice partials][mean, rstd][s1, s2][m1, m2]
 size_t use_op_gn_workspace(int B, int C, int groups) { return (B < 1 || C < 1 || groups < 1) ? 0 : gn_workspace_floats(B, C, groups); }
-int use_op_gn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, int groups, float eps, int act, const float* add,
-                      float add_scale, int B, int HW, int C, float* work, float* dx, float* dgamma, float* dbeta, use_stream_t stream) {
+int use_op_gn_act_bwd(const void* x, const void* dy, int dtype, const float* gamma, const float* beta, int groups, float eps, int act, const void* add,
+                      float add_scale, int B, int HW, int C, float* work, void* dx, float* dgamma, float* dbeta, use_stream_t stream) {
     if (!x || !dy || !gamma || !beta || !work || !dx || !dgamma || !dbeta || groups < 1 || C % groups) return fail(USE_E_INVALID, "use_op_gn_act_bwd: bad argument");
+    if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_F16) return fail(USE_E_INVALID, "use_op_gn_act_bwd: bad dtype");
     if ((uintptr_t)work % 8) return fail(USE_E_INVALID, "use_op_gn_act_bwd: workspace must be 8-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     double* part = (double*)work;
     float* mean = work + (size_t)4 * B * GN_MAX_SLICES * std::max(C, groups); float* rstd = mean + (size_t)B * groups;
     float* s1 = rstd + (size_t)B * groups; float* s2 = s1 + (size_t)B * C; float* m12 = s2 + (size_t)B * C;
-    launch_gn_stats(x, B, HW, C, groups, eps, mean, rstd, part, s);
-    launch_gn_act_bwd(x, dy, mean, rstd, gamma, beta, act, add, add_scale, B, HW, C, groups, s1, s2, m12, part, dx, dgamma, dbeta, s);
+    if (!launch_gn_stats(x, dtype, B, HW, C, groups, eps, mean, rstd, part, s) ||
+        !launch_gn_act_bwd(x, dy, dtype, mean, rstd, gamma, beta, act, add, add_scale, B, HW, C, groups, s1, s2, m12, part, dx, dgamma, dbeta, s))
+        return fail(USE_E_INVALID, "use_op_gn_act_bwd: 16-bit tensors need C to be a multiple of 8 (and C / 8 <= 256)");
     HIPCHK(hipGetLastError());
     return USE_OK;
 }
-int use_op_gn_act_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, int act, int B, int HW, int C, float* work,
-                      float* y, use_stream_t stream) {
+int use_op_gn_act_fwd(const void* x, int dtype, const float* gamma, const float* beta, int groups, float eps, int act, int B, int HW, int C, float* work,
+                      void* y, use_stream_t stream) {
     if (!x || !gamma || !beta || !work || !y || groups < 1 || C % groups) return fail(USE_E_INVALID, "use_op_gn_act_fwd: bad argument");
+    if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_F16) return fail(USE_E_INVALID, "use_op_gn_act_fwd: bad dtype");
     if ((uintptr_t)work % 8) return fail(USE_E_INVALID, "use_op_gn_act_fwd: workspace must be 8-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     double* part = (double*)work;
     float* mean = work + (size_t)4 * B * GN_MAX_SLICES * std::max(C, groups); float* rstd = mean + (size_t)B * groups;
-    launch_gn_stats(x, B, HW, C, groups, eps, mean, rstd, part, s);
-    launch_gn_act_fwd(x, mean, rstd, gamma, beta, act, B, HW, C, groups, y, s);
+    if (!launch_gn_stats(x, dtype, B, HW, C, groups, eps, mean, rstd, part, s) ||
+        !launch_gn_act_fwd(x, dtype, mean, rstd, gamma, beta, act, B, HW, C, groups, y, s))
+        return fail(USE_E_INVALID, "use_op_gn_act_fwd: 16-bit tensors need C to be a multiple of 8 (and C / 8 <= 256)");
     HIPCHK(hipGetLastError());
     return USE_OK;
 }

@@ -163,18 +163,20 @@ void launch_score_out(const float* pyr, int pc, const float* t, int t_stride, co
 // work = nullptr: the 32 x 32-tile kernel with atomic slices; else wgrad_workspace_floats() floats of scratch for the tiled kernel
 size_t wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin, int ntaps);
 void wgrad_set_blocks(int n);                 // target workgroup count of the tiled weight-gradient kernel (tiles x pixel slices)
-void launch_wgrad(const float* dy, const float* x, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
+// dy / x in `dtype` (fp32 / bf16 / fp16 storage; converted while staging, exact-fp32 MFMA); false: case not served (16-bit without workspace)
+bool launch_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
                   float* work, hipStream_t s);                            // dW [Cout][Cin][ntaps] (reference layout), db [Cout] or null
-// part (fp64 scratch of gn_workspace_floats) = nullptr: the one-block-per-(item, group) forms
-void launch_gn_stats(const float* x, int B, int HW, int C, int G, float eps, float* mean, float* rstd, double* part, hipStream_t s);
+// GroupNorm(+SiLU) with a tape: x / dy / y / dx / add in `dtype`, statistics and affine parameters fp32.
+// part (fp64 scratch of gn_workspace_floats) = nullptr: the one-block-per-(item, group) forms (fp32 only); false: case not served
+bool launch_gn_stats(const void* x, int dtype, int B, int HW, int C, int G, float eps, float* mean, float* rstd, double* part, hipStream_t s);
 constexpr int GN_MAX_SLICES = 256;            // pixel slices per item of the sliced GroupNorm reductions (fp64 partials per slice)
 size_t gn_workspace_floats(int B, int C, int G);
 // dx = d/dx of act(GroupNorm(x)) against dy, + add_scale * add (or add == null); s1 / s2: [B][C] scratch; dgamma / dbeta [C]
-void launch_gn_act_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
-                       const float* add, float add_scale, int B, int HW, int C, int G, float* s1, float* s2, float* m12, double* part, float* dx,
+bool launch_gn_act_bwd(const void* x, const void* dy, int dtype, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                       const void* add, float add_scale, int B, int HW, int C, int G, float* s1, float* s2, float* m12, double* part, void* dx,
                        float* dgamma, float* dbeta, hipStream_t s);
-void launch_gn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int B, int HW, int C,
-                       int G, float* y, hipStream_t s);
+bool launch_gn_act_fwd(const void* x, int dtype, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int B, int HW,
+                       int C, int G, void* y, hipStream_t s);
 void launch_colsum(const float* x, int B, int HW, int C, float scale, float* out, hipStream_t s);       // out[b][c] = scale * sum_p x[b,p,c]
 // attention core backward (q, k, v, dO, dq, dk, dv: [B][N][C] fp32; work: 2 B N N floats)
 void launch_attention_bwd(const float* q, const float* k, const float* v, const float* dO, float* work, float* dq, float* dk, float* dv, int B,

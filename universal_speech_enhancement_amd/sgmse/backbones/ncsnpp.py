@@ -90,6 +90,7 @@ class NCSNpp(nn.Module):
                     node.add_module(p, _Holder())
                 node = getattr(node, p)
             node.register_parameter(parts[-1], nn.Parameter(val, requires_grad=False))
+        self.train_precision = "fp32"     # "bf16" / "fp16": mixed-precision taped forward (training.ncsnpp_forward_train)
         self._engine = None
         self._engine_sde = self._DEFAULT_SDE
         self._engine_dirty = True
@@ -147,7 +148,8 @@ class NCSNpp(nn.Module):
         return any(p.requires_grad for p in self.parameters())
 
     def forward_train(self, x: torch.Tensor, time_cond: torch.Tensor = None) -> torch.Tensor:
-        """The same network with a tape (fp32, operators of libuse_hip.so forward and backward: ``training.ncsnpp_forward_train``);
+        """The same network with a tape (operators of libuse_hip.so forward and backward: ``training.ncsnpp_forward_train``; fp32, or
+        mixed precision with ``self.train_precision = "bf16"``);
         what ``forward`` runs when gradients are enabled and the parameters are trainable.  The sampling engine's weight copy is marked
         stale: an optimiser step is assumed to follow."""
         from ...training import ncsnpp_forward_train
@@ -156,8 +158,9 @@ class NCSNpp(nn.Module):
             from ...hip_engine import UseHipError
             raise UseHipError("NCSN++ (HIP) training needs the parameters on the GPU (module.to('cuda')): there is no CPU implementation")
         self._engine_dirty, self._weight_file = True, None
+        cd = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[self.train_precision]
         return ncsnpp_forward_train(P, x, time_cond, self.ch_mult, self.num_res_blocks, conditional=self.conditional,
-                                    scale_by_sigma=self.scale_by_sigma)
+                                    scale_by_sigma=self.scale_by_sigma, compute_dtype=cd)
 
     def forward(self, x: torch.Tensor, time_cond: torch.Tensor = None) -> torch.Tensor:
         nin = self.input_channels // 2

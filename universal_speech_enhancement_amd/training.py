@@ -32,12 +32,14 @@ from . import training_ops as ops
 SQRT1_2 = 0.70710678118654752440
 
 
-def _conv_dev(x, w, b, w_mode, ntaps, cout, scale=1.0):
-    """``use_op_conv_dev``: x [B,H,W,Cin] fp32 NHWC, w / b fp32 DEVICE parameter tensors."""
+def _conv_dev(x, w, b, w_mode, ntaps, cout, scale=1.0, out_dtype=None):
+    """``use_op_conv_dev``: x [B,H,W,Cin] NHWC in fp32 / bf16 / fp16 storage (the MFMA operand type), w / b fp32 DEVICE parameter tensors
+    (laid out in x's type on the device); the result in ``out_dtype`` (default: x's)."""
     B, H, W, Cin = x.shape
-    out = torch.empty(B, H, W, cout, dtype=torch.float32, device=x.device)
+    out = torch.empty(B, H, W, cout, dtype=out_dtype or x.dtype, device=x.device)
     op = UseConvOp()
-    op.B, op.H, op.W, op.C0, op.C1, op.Cout, op.ntaps, op.act, op.dtype, op.out_dtype, op.variant = B, H, W, Cin, 0, cout, ntaps, 0, 0, 0, 0
+    op.B, op.H, op.W, op.C0, op.C1, op.Cout, op.ntaps, op.act, op.variant = B, H, W, Cin, 0, cout, ntaps, 0, 0
+    op.dtype, op.out_dtype = ops.dtype_code(x), ops.dtype_code(out)
     op.src0, op.w, op.bias = x.data_ptr(), w.data_ptr(), (b.data_ptr() if b is not None else None)
     op.out_scale, op.out = scale, out.data_ptr()
     lib = _lib.lib()
@@ -53,19 +55,19 @@ class _Conv(torch.autograd.Function):
     [Cin][Cout] (layers.py:639-650).  Channel counts are multiples of 32 (the caller zero-pads the 2/4/6-channel ends of the network)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, out_dtype=None):
         x, w = x.contiguous(), w.contiguous()
         nin = w.dim() == 2
         ntaps = 1 if nin or w.shape[2] == 1 else 9
         cout = w.shape[1] if nin else w.shape[0]
         ctx.save_for_backward(x, w)
         ctx.nin, ctx.ntaps, ctx.has_bias = nin, ntaps, b is not None
-        return _conv_dev(x, w, b, 2 if nin else 0, ntaps, cout)
+        return _conv_dev(x, w, b, 2 if nin else 0, ntaps, cout, out_dtype=out_dtype)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gy = gy.contiguous()
+        gy = gy.to(x.dtype).contiguous()            # the layer's operand type (the 2/4/6-channel ends of a 16-bit network change type)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             # NIN: dx = dy W^T, i.e. a 1x1 conv whose [cout][cin] weight is W itself; conv: the flipped, transposed weight (w_mode 1)
@@ -74,7 +76,7 @@ class _Conv(torch.autograd.Function):
             dw, db = ops.conv_wgrad(gy, x, ntaps=ctx.ntaps, with_bias=ctx.has_bias)
             gw = dw.t().contiguous() if ctx.nin else dw.view(w.shape)
             gb = db
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 class _GNAct(torch.autograd.Function):
@@ -119,8 +121,9 @@ class _AttnCore(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gO):
-        q, k, v = ctx.saved_tensors
-        return ops.attention_core_bwd(q, k, v, gO.contiguous())
+        q, k, v = ctx.saved_tensors                  # the backward kernels are fp32 (N <= 16 tokens at the training shapes)
+        dq, dk, dv = ops.attention_core_bwd(q.float(), k.float(), v.float(), gO.float().contiguous())
+        return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype)
 
 
 conv, gn_act, fir, attn_core = _Conv.apply, _GNAct.apply, _Fir.apply, _AttnCore.apply
@@ -146,7 +149,7 @@ def _resblock(x, temb_act, P, p, up=False, down=False):
         h, x = fir(h, up), fir(x, up)
     h = conv(h, P[p + ".Conv_0.weight"], P[p + ".Conv_0.bias"])
     if temb_act is not None:
-        h = h + F.linear(temb_act, P[p + ".Dense_0.weight"], P[p + ".Dense_0.bias"])[:, None, None, :]
+        h = h + F.linear(temb_act, P[p + ".Dense_0.weight"], P[p + ".Dense_0.bias"]).to(h.dtype)[:, None, None, :]
     h = _gn(h, P, p + ".GroupNorm_1", 1)
     h = conv(h, P[p + ".Conv_1.weight"], P[p + ".Conv_1.bias"])
     if (p + ".Conv_2.weight") in P:
@@ -164,10 +167,14 @@ def _attn_block(x, P, p):
 
 
 def ncsnpp_forward_train(P: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, ch_mult: Sequence[int], num_res_blocks: int,
-                         conditional: bool = True, scale_by_sigma: bool = True) -> torch.Tensor:
+                         conditional: bool = True, scale_by_sigma: bool = True, compute_dtype=torch.float32) -> torch.Tensor:
     """``NCSNpp.forward`` (ncsnpp.py:324-501) with a tape.  P: the backbone's parameters under the reference's state-dict names
     (fp32, on the GPU); x complex64 [B, n, F, T'] (n = 2: cat[x_t, Y]; 3: + Y_denoised; 1: discriminative network, conditional = scale_by_sigma = False); t float32 [B].
-    Returns complex64 [B, 1, F, T']."""
+    ``compute_dtype`` torch.bfloat16 / float16: mixed precision - activations and their gradients stored in 16 bits, convolutions (forward
+    and data gradient) on the 16-bit MFMA kernels with the fp32 parameters laid out in that type per call; parameters, parameter
+    gradients (exact-fp32 MFMA contraction of the 16-bit tensors), GroupNorm statistics, the time embedding, the 2/4/6-channel input and
+    output pyramids and the loss stay fp32.  Returns complex64 [B, 1, F, T']."""
+    cd = compute_dtype
     if not x.is_cuda:
         from .hip_engine import UseHipError
         raise UseHipError("NCSN++ (HIP) needs CUDA/ROCm tensors: the network has no CPU implementation")
@@ -188,7 +195,7 @@ def ncsnpp_forward_train(P: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.T
         temb_act = F.silu(F.linear(F.silu(e), P["all_modules.2.weight"], P["all_modules.2.bias"]))   # every consumer takes SiLU(temb)
         m = 3
     pyr_in = x4
-    hs = [conv(x4, _pad_to(P[f"all_modules.{m}.weight"], 1, 32), P[f"all_modules.{m}.bias"])]
+    hs = [conv(x4, _pad_to(P[f"all_modules.{m}.weight"], 1, 32), P[f"all_modules.{m}.bias"], cd)]
     m += 1
     for lvl in range(L):
         for _ in range(num_res_blocks):
@@ -196,7 +203,7 @@ def ncsnpp_forward_train(P: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.T
         if lvl != L - 1:
             h = _resblock(hs[-1], temb_act, P, f"all_modules.{m}", down=True); m += 1
             pyr_in = fir(pyr_in, False)                                                         # ncsnpp.py:404
-            h = conv(pyr_in, _pad_to(P[f"all_modules.{m}.Conv_0.weight"], 1, 32), P[f"all_modules.{m}.Conv_0.bias"]) + h   # Combine 'sum'
+            h = conv(pyr_in, _pad_to(P[f"all_modules.{m}.Conv_0.weight"], 1, 32), P[f"all_modules.{m}.Conv_0.bias"], cd) + h   # Combine 'sum'
             m += 1
             hs.append(h)
     h = _resblock(hs[-1], temb_act, P, f"all_modules.{m}"); m += 1
@@ -207,7 +214,7 @@ def ncsnpp_forward_train(P: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.T
         for _ in range(num_res_blocks + 1):
             h = _resblock(torch.cat([h, hs.pop()], dim=3), temb_act, P, f"all_modules.{m}"); m += 1
         ph = _gn(h, P, f"all_modules.{m}", 1); m += 1                                           # ncsnpp.py:443,457
-        ph = conv(ph, _pad_to(P[f"all_modules.{m}.weight"], 0, 32), _pad_to(P[f"all_modules.{m}.bias"], 0, 32)); m += 1
+        ph = conv(ph, _pad_to(P[f"all_modules.{m}.weight"], 0, 32), _pad_to(P[f"all_modules.{m}.bias"], 0, 32), torch.float32); m += 1
         pyramid = ph if pyramid is None else fir(pyramid, True) + ph                            # ncsnpp.py:456-461
         if lvl != 0:
             h = _resblock(h, temb_act, P, f"all_modules.{m}", up=True); m += 1

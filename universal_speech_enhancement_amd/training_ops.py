@@ -36,6 +36,14 @@ def _pad32(c):
     return (c + 31) // 32 * 32
 
 
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def dtype_code(t):
+    """The library's storage-type code of a tensor (0 fp32, 1 bf16, 2 fp16)."""
+    return _DT[t.dtype]
+
+
 def conv_fwd(x, w, bias=None, coef=None, act=0, temb=None, res=None, x0=None, w2=None, scale=1.0, ntaps=9, stats=None):
     """The library's fused convolution on fp32 NHWC tensors whose channel counts are multiples of 32 (``use_op_conv``)."""
     B, H, W, Cin = x.shape
@@ -68,26 +76,29 @@ def conv_dgrad(dy, w, scale=1.0):
 
 
 def conv_wgrad(dy, x, ntaps=9, alpha=1.0, with_bias=True, tiled=True):
-    """dW [Cout][Cin][3][3] (or [Cout][Cin]) and db of y = conv(x, w) + b from dy (``use_op_wgrad``); ``tiled=False``: the small-tile
-    kernel with atomic accumulation."""
+    """dW [Cout][Cin][3][3] (or [Cout][Cin]) and db (fp32) of y = conv(x, w) + b from dy (``use_op_wgrad``); dy and x share a storage
+    type (fp32 / bf16 / fp16; the contraction is exact-fp32 MFMA either way).  ``tiled=False``: the small-tile kernel with atomic
+    accumulation (fp32 only)."""
     B, H, W, Cout = dy.shape
     Cin = x.shape[3]
+    assert dy.dtype == x.dtype
     dw = torch.empty(Cout, Cin, *((3, 3) if ntaps == 9 else ()), dtype=torch.float32, device=dy.device)
     db = torch.empty(Cout, dtype=torch.float32, device=dy.device) if with_bias else None
     lib = _lib.lib()
     n = lib.use_op_wgrad_workspace(B, H, W, Cout, Cin, ntaps) if tiled else 0
     work = torch.empty(n, dtype=torch.float32, device=dy.device) if n else None
-    check(lib.use_op_wgrad(_p(dy), _p(x), _p(dw), _p(db), B, H, W, Cout, Cin, ntaps, alpha, _p(work), n, _stream()), "use_op_wgrad")
+    check(lib.use_op_wgrad(_p(dy), _p(x), dtype_code(x), _p(dw), _p(db), B, H, W, Cout, Cin, ntaps, alpha, _p(work), n, _stream()), "use_op_wgrad")
     return dw, db
 
 
 def gn_act_bwd(x, dy, gamma, beta, groups, act=1, add=None, add_scale=1.0, eps=1e-6):
     B, H, W, Cc = x.shape
+    assert dy.dtype == x.dtype and (add is None or add.dtype == x.dtype)
     work = torch.empty(_lib.lib().use_op_gn_workspace(B, Cc, groups), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     dg, dbt = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
-    check(_lib.lib().use_op_gn_act_bwd(_p(x), _p(dy), _p(gamma), _p(beta), groups, eps, act, _p(add), add_scale, B, H * W, Cc, _p(work), _p(dx),
-                                        _p(dg), _p(dbt), _stream()), "use_op_gn_act_bwd")
+    check(_lib.lib().use_op_gn_act_bwd(_p(x), _p(dy), dtype_code(x), _p(gamma), _p(beta), groups, eps, act, _p(add), add_scale, B, H * W, Cc,
+                                        _p(work), _p(dx), _p(dg), _p(dbt), _stream()), "use_op_gn_act_bwd")
     return dx, dg, dbt
 
 
@@ -96,17 +107,18 @@ def gn_act_fwd(x, gamma, beta, groups, act=1, eps=1e-6):
     B, H, W, Cc = x.shape
     work = torch.empty(_lib.lib().use_op_gn_workspace(B, Cc, groups), dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
-    check(_lib.lib().use_op_gn_act_fwd(_p(x), _p(gamma), _p(beta), groups, eps, act, B, H * W, Cc, _p(work), _p(y), _stream()), "use_op_gn_act_fwd")
+    check(_lib.lib().use_op_gn_act_fwd(_p(x), dtype_code(x), _p(gamma), _p(beta), groups, eps, act, B, H * W, Cc, _p(work), _p(y), _stream()),
+          "use_op_gn_act_fwd")
     return y
 
 
 def fir(x, up):
-    """upsample_2d / downsample_2d of an fp32 NHWC tensor (``use_op_fir``).  The two are mutual transposes up to the gain:
-    backward(upsample_2d)(g) = 4 downsample_2d(g), backward(downsample_2d)(g) = upsample_2d(g) / 4."""
+    """upsample_2d / downsample_2d of an NHWC tensor (``use_op_fir``; fp32 / bf16 / fp16 storage).  The two are mutual transposes up to the
+    gain: backward(upsample_2d)(g) = 4 downsample_2d(g), backward(downsample_2d)(g) = upsample_2d(g) / 4."""
     B, H, W, Cc = x.shape
     H2, W2 = (H * 2, W * 2) if up else (H // 2, W // 2)
-    out = torch.empty(B, H2, W2, Cc, dtype=torch.float32, device=x.device)
-    check(_lib.lib().use_op_fir(_p(x), 0, None, 0, None, _p(out), B, H, W, Cc, int(up), _stream()), "use_op_fir")
+    out = torch.empty(B, H2, W2, Cc, dtype=x.dtype, device=x.device)
+    check(_lib.lib().use_op_fir(_p(x), dtype_code(x), None, 0, None, _p(out), B, H, W, Cc, int(up), _stream()), "use_op_fir")
     return out
 
 
@@ -157,10 +169,10 @@ def resblock_backward(x, h1, temb, gy, W, groups0, groups1, up=False, down=False
 
 
 def attention_core(q, k, v):
-    """softmax(q k^T / sqrt(C)) v on [B,N,C] fp32 tensors (``use_op_attention``)."""
+    """softmax(q k^T / sqrt(C)) v on [B,N,C] tensors (``use_op_attention``; fp32 / bf16 / fp16 storage)."""
     B, N, Cc = q.shape
     out = torch.empty_like(q)
-    check(_lib.lib().use_op_attention(_p(q), _p(k), _p(v), _p(out), 0, B, N, Cc, _stream()), "use_op_attention")
+    check(_lib.lib().use_op_attention(_p(q), _p(k), _p(v), _p(out), dtype_code(q), B, N, Cc, _stream()), "use_op_attention")
     return out
 
 
