@@ -231,7 +231,7 @@ int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C
  * use_op_colsum:     out[b][c] = scale * sum_p x[b,p,c]            (the gradient reaching Dense_0's output)
  * use_op_dense_bwd:  Dense_0(SiLU(temb)): g [B][Cout] -> dW [Cout][K], db [Cout], dtemb [B][K].
  * use_op_attention_bwd: the AttnBlockpp core, out = softmax(q k^T / sqrt(C)) v: dq, dk, dv from dO ([B][N][C] each; work: 2 B N N floats). */
-size_t use_op_wgrad_workspace(int B, int H, int W, int Cout, int Cin, int ntaps);
+size_t use_op_wgrad_workspace(int B, int H, int W, int Cout, int Cin, int ntaps, int dtype);
 int use_op_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
                  float* work, size_t work_floats, use_stream_t stream);
 size_t use_op_gn_workspace(int B, int C, int groups);

@@ -107,3 +107,38 @@ def test_attention_block_gradients_match_the_reference_backward(golden_dir):
         e = float((got - want).abs().max() / want.abs().max())
         print(f"[measured] attn grad {k}: {e:.3g}")
         assert e < 1e-4, (k, e)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W,Cout,Cin,ntaps", [(2, 12, 10, 32, 32, 9), (1, 16, 8, 64, 96, 9), (3, 4, 1, 128, 64, 9), (2, 32, 48, 96, 128, 9),
+                                                  (2, 24, 6, 64, 64, 1), (1, 64, 64, 128, 128, 9), (2, 8, 3, 32, 64, 9), (2, 4, 2, 256, 128, 1), (1, 2, 1, 64, 64, 1)])
+def test_weight_gradient_on_the_16bit_matrix_pipe(dt, B, H, W, Cout, Cin, ntaps):
+    """wgrad16_kernel (16-bit MFMA, transposing LDS reads) against (a) the fp32-MFMA kernel on the same 16-bit tensors (identical
+    products, fp32 accumulation: agreement to summation order, 2e-6 of the largest entry) and (b) torch's fp64 contraction of them."""
+    from universal_speech_enhancement_amd import training_ops as T
+    from universal_speech_enhancement_amd.hip_engine import set_option
+    g = torch.Generator().manual_seed(H * 131 + W)
+    dy = (torch.randn(B, H, W, Cout, generator=g) * 0.5).to(dt).cuda()
+    x = torch.randn(B, H, W, Cin, generator=g).to(dt).cuda()
+    try:
+        set_option("wgrad_mfma16", 1)
+        dw16, db16 = T.conv_wgrad(dy, x, ntaps=ntaps, alpha=0.75)
+        set_option("wgrad_mfma16", 0)
+        dw32, db32 = T.conv_wgrad(dy, x, ntaps=ntaps, alpha=0.75)
+    finally:
+        set_option("wgrad_mfma16", 1)
+    torch.cuda.synchronize()
+    dyd, xd = dy.double().cpu(), x.double().cpu()
+    if ntaps == 9:
+        xp = torch.nn.functional.pad(xd, (0, 0, 1, 1, 1, 1))
+        ref = torch.stack([torch.einsum("bhwo,bhwi->oi", dyd, xp[:, ky:ky + H, kx:kx + W]) for ky in range(3) for kx in range(3)], dim=-1)
+        ref = ref.view(Cout, Cin, 3, 3) * 0.75
+    else:
+        ref = torch.einsum("bhwo,bhwi->oi", dyd, xd) * 0.75
+    scale = float(ref.abs().max())
+    assert torch.isfinite(dw16).all() and torch.isfinite(db16).all()
+    assert float((dw16 - dw32).abs().max()) < 2e-6 * scale
+    assert float((dw16.double().cpu() - ref).abs().max()) < 2e-6 * scale
+    refb = dyd.sum((0, 1, 2)) * 0.75
+    assert float((db16.double().cpu() - refb).abs().max()) < 2e-6 * float(refb.abs().max()) + 1e-6
+    assert float((db16 - db32).abs().max()) < 2e-6 * float(refb.abs().max()) + 1e-6

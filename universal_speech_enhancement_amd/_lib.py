@@ -93,7 +93,7 @@ SYMBOLS = {
     "use_op_fir": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "use_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "use_op_gn_finalize": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _i, _vp]),
-    "use_op_wgrad_workspace": (C.c_size_t, [_i, _i, _i, _i, _i, _i]),
+    "use_op_wgrad_workspace": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i]),
     "use_op_wgrad": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, C.c_size_t, _vp]),
     "use_op_gn_workspace": (C.c_size_t, [_i, _i, _i]),
     "use_op_gn_act_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _f, _i, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

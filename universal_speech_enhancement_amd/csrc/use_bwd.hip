@@ -184,6 +184,129 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const T* __restrict_
         if (hh == 0 && co0 + wm * 32 + l31 < Cout) bpart[(size_t)blockIdx.y * Cout + co0 + wm * 32 + l31] = bsum;
     }
 }
+// ---- weight gradient of 16-bit tensors on the 16-bit matrix pipe (mixed-precision training) -------------------------------------------
+// Same decomposition as wgrad_tile_kernel (64 co x 64 ci tile, all taps, pixel slices, fp32 partial tiles), but the contraction runs on
+// v_mfma_f32_32x32x16_{bf16,f16}: 16 pixels per instruction at 16x the fp32 rate.  The MFMA wants 8 consecutive k (= pixels) per lane for
+// one channel, the NHWC data has the channels contiguous: the chunk ([64 px][64 co]) and the halo patch ([px][64 ci]) are staged in LDS
+// as they lie in memory (plain 16-byte copies, row pitch 96 elements = 192 B so that the four rows of a transposing read fall into four
+// different 64-byte bank groups) and read with ds_read_b64_tr_b16: a 16-lane group fetches a [4 px][16 ch] block and every lane receives
+// 4 pixels of its own channel (lane i passes the address of row i >> 2, channel quad i & 3; measured: scripts/experiments/tr_probe.hip).
+// Chunks are RH x CW = 8 x 8 pixels where the map allows (halo patch 100 px instead of 198 for 1 x 64); the tap shift is a row offset
+// in the patch, i.e. an address offset - no alignment constraint.  Products of 16-bit values are exact in fp32: same numerics as the
+// fp32-MFMA kernel on the same data, up to the summation order.
+constexpr int WH_PITCH = 96;                                                     // LDS row pitch in elements (192 B)
+constexpr int WH_SMEM = (WG_PX + WG_PATCH) * WH_PITCH * 2 + WG_PX * 4;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+template <typename T>
+DEVI typename Mfma<T>::frag ld_tr8(const char* p0, const char* p1) {            // 8 k-values of this lane's channel: two transposing reads
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    const s16x8 c = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(typename Mfma<T>::frag, c);
+}
+
+template <int NT, typename T>
+__global__ __launch_bounds__(256, 2) void wgrad16_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ part,
+                                                         float* __restrict__ bpart, int B, int H, int W, int Cout, int Cin, WgradPlan q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* dyS = smem;                                                   // [64 px][pitch] T
+    char* xS = dyS + WG_PX * WH_PITCH * 2;                              // [(RH + 2)(CW + 2) px][pitch] T
+    int* pofs = reinterpret_cast<int*>(xS + WG_PATCH * WH_PITCH * 2);   // patch pixel of chunk pixel j (centre tap); beyond the chunk: pixel 0's
+                                                                        // (always staged: dY is zero there, but 0 x stale LDS bits could be NaN)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int tiles_ci = (Cin + WG_T - 1) / WG_T;
+    const int co0 = (blockIdx.x / tiles_ci) * WG_T, ci0 = (blockIdx.x % tiles_ci) * WG_T;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int PWp = q.CW + 2, npatch = (q.RH + 2) * PWp, nchunk = q.RH * q.CW;
+    if (t < WG_PX) pofs[t] = t < nchunk ? (t / q.CW + 1) * PWp + t % q.CW + 1 : PWp + 1;
+    __syncthreads();
+    // this lane's rows of the transposing reads: k = 16 ks + 8 (lane >> 5) + 4 r + (i >> 2), i = lane & 15; channels 16 ((lane >> 4) & 1) + 4 (i & 3)
+    const int li = lane & 15, chq = (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+    int aoff[4][2], boff[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = 16 * ks + 8 * hh + 4 * r + (li >> 2);
+            aoff[ks][r] = j * WH_PITCH * 2 + wm * 64 + chq;
+            boff[ks][r] = pofs[j] * WH_PITCH * 2 + wn * 64 + chq;
+        }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    float bsum = 0.f;
+    const bool want_b = bpart && ci0 == 0 && wn == 0;
+    const int u_lo = blockIdx.y * q.per_slice, u_hi = min(u_lo + q.per_slice, q.units);
+    const int rows_per_img = H / q.RH;
+    for (int u = u_lo; u < u_hi; ++u) {
+        const int cx = u % q.chunks_x, rr = u / q.chunks_x;
+        const int b = rr / rows_per_img, y0 = (rr % rows_per_img) * q.RH, x0 = cx * q.CW;
+        __syncthreads();                                                // the previous chunk's MFMAs are done with the LDS
+        for (int e = t; e < WG_PX * (WG_T / 8); e += 256) {             // dY chunk, 16-byte pieces
+            const int j = e / (WG_T / 8), c8 = (e % (WG_T / 8)) * 8;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            const int r = j / q.CW, cxx = x0 + j % q.CW;
+            if (j < nchunk && cxx < W && co0 + c8 < Cout) v = *reinterpret_cast<const uint4*>(dy + (((size_t)b * H + y0 + r) * W + cxx) * Cout + co0 + c8);
+            *reinterpret_cast<uint4*>(dyS + (j * WH_PITCH + c8) * 2) = v;
+        }
+        if (NT == 9) {
+            for (int e = t; e < npatch * (WG_T / 8); e += 256) {        // X patch with a one-pixel halo, zero outside the image
+                const int pp = e / (WG_T / 8), c8 = (e % (WG_T / 8)) * 8;
+                const int yy = y0 + pp / PWp - 1, xx = x0 + pp % PWp - 1;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W && ci0 + c8 < Cin) v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + yy) * W + xx) * Cin + ci0 + c8);
+                *reinterpret_cast<uint4*>(xS + (pp * WH_PITCH + c8) * 2) = v;
+            }
+        } else {
+            for (int e = t; e < WG_PX * (WG_T / 8); e += 256) {         // 1x1: the chunk's own pixels at their patch positions
+                const int j = e / (WG_T / 8), c8 = (e % (WG_T / 8)) * 8;
+                const int r = j / q.CW, cxx = x0 + j % q.CW;
+                if (j < nchunk) {
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (cxx < W && ci0 + c8 < Cin) v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + y0 + r) * W + cxx) * Cin + ci0 + c8);
+                    *reinterpret_cast<uint4*>(xS + (((r + 1) * PWp + j % q.CW + 1) * WH_PITCH + c8) * 2) = v;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const typename Mfma<T>::frag a = ld_tr8<T>(dyS + aoff[ks][0], dyS + aoff[ks][1]);
+            if (want_b) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bsum += (float)a[k];
+            }
+            if (NT == 9) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int sh = ((k / 3 - 1) * PWp + (k % 3 - 1)) * WH_PITCH * 2;
+                    const typename Mfma<T>::frag bv = ld_tr8<T>(xS + boff[ks][0] + sh, xS + boff[ks][1] + sh);
+                    acc[k] = Mfma<T>::mma(a, bv, acc[k]);                // D[co][ci] += sum_k dY[k][co] X[k + tap][ci]
+                }
+            } else {
+                acc[0] = Mfma<T>::mma(a, ld_tr8<T>(xS + boff[ks][0], xS + boff[ks][1]), acc[0]);
+            }
+        }
+    }
+    float* o = part + (size_t)blockIdx.y * Cout * Cin * NT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, ci = ci0 + wn * 32 + l31;
+        if (co < Cout && ci < Cin) {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) o[((size_t)co * Cin + ci) * NT + k] = acc[k][r];
+        }
+    }
+    if (want_b) {                                                      // bias gradient: column sums of dY, once per co tile and slice
+        bsum += __shfl_xor(bsum, 32);
+        if (hh == 0 && co0 + wm * 32 + l31 < Cout) bpart[(size_t)blockIdx.y * Cout + co0 + wm * 32 + l31] = bsum;
+    }
+}
+
 // out[i] = alpha * sum over the slices of part[slice][i]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nslices, long n, float alpha, float* __restrict__ out) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -601,9 +724,9 @@ void launch_attention_bwd(const float* q, const float* k, const float* v, const 
 }
 static int g_wgrad_blocks = 512;      // two workgroups per CU in one round (101 vs 105 ms per training step with 1024)
 void wgrad_set_blocks(int n) { g_wgrad_blocks = n > 0 ? n : 512; }
-static WgradPlan wgrad_plan(int B, int H, int W, int Cout, int Cin) {
+static WgradPlan wgrad_plan(int B, int H, int W, int Cout, int Cin, int cw_max = WG_PX) {
     WgradPlan q;
-    q.CW = std::min(W, WG_PX);
+    q.CW = std::min(W, cw_max);
     q.RH = std::min(WG_PX / q.CW, H);
     while (H % q.RH) --q.RH;                                          // a chunk stays inside one image
     q.chunks_x = (W + q.CW - 1) / q.CW;
@@ -615,9 +738,12 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Cout, int Cin) {
     q.nslices = (q.units + q.per_slice - 1) / q.per_slice;
     return q;
 }
-size_t wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin, int ntaps) {
+static int g_wgrad_mfma16 = 1;        // 16-bit tensors: 1 = wgrad16_kernel (16-bit MFMA), 0 = wgrad_tile_kernel (converted while staging, fp32 MFMA)
+void wgrad_set_mfma16(int v) { g_wgrad_mfma16 = v; }
+static bool wgrad_use16(int dtype, int Cout, int Cin) { return dtype != DT_F32 && g_wgrad_mfma16 && Cout % 8 == 0 && Cin % 8 == 0; }
+size_t wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin, int ntaps, int dtype) {
     if (Cout % 4 || Cin % 4) return 0;
-    const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin);
+    const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin, wgrad_use16(dtype, Cout, Cin) ? 8 : WG_PX);
     return (size_t)q.nslices * ((size_t)Cout * Cin * ntaps + Cout);
 }
 template <typename T>
@@ -633,15 +759,32 @@ static void wgrad_tile_t(const void* dy, const void* x, float* part, float* bpar
     if (ntaps == 9) hipLaunchKernelGGL((wgrad_tile_kernel<9, T>), grid, dim3(256), WG_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
     else            hipLaunchKernelGGL((wgrad_tile_kernel<1, T>), grid, dim3(256), WG_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
 }
-// dy / x in `dtype` (converted to fp32 while staging: the contraction is exact-fp32 MFMA either way); dw / db fp32.  16-bit inputs need the
+template <typename T>
+static void wgrad16_t(const void* dy, const void* x, float* part, float* bpart, int B, int H, int W, int Cout, int Cin, int ntaps, const WgradPlan& q,
+                      hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel<9, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WH_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel<1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WH_SMEM);
+        attr = true;
+    }
+    const dim3 grid(((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T), q.nslices);
+    if (ntaps == 9) hipLaunchKernelGGL((wgrad16_kernel<9, T>), grid, dim3(256), WH_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
+    else            hipLaunchKernelGGL((wgrad16_kernel<1, T>), grid, dim3(256), WH_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
+}
+// dy / x in `dtype`: 16-bit tensors on the 16-bit matrix pipe (wgrad16_kernel), fp32 on the exact-fp32 one; dw / db fp32.  16-bit inputs need the
 // tiled kernel (work != nullptr, channel counts multiples of 4): returns false otherwise.
 bool launch_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
                   float* work, hipStream_t s) {
     if (work && Cout % 4 == 0 && Cin % 4 == 0) {
-        const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin);
+        const bool m16 = wgrad_use16(dtype, Cout, Cin);
+        const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin, m16 ? 8 : WG_PX);
         const long n = (long)Cout * Cin * ntaps;
         float* part = work; float* bpart = work + (size_t)q.nslices * n;
-        if (dtype == DT_F32) wgrad_tile_t<float>(dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, ntaps, q, s);
+        if (m16) {
+            if (dtype == DT_BF16) wgrad16_t<__bf16>(dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, ntaps, q, s);
+            else wgrad16_t<_Float16>(dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, ntaps, q, s);
+        } else if (dtype == DT_F32) wgrad_tile_t<float>(dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, ntaps, q, s);
         else if (dtype == DT_BF16) wgrad_tile_t<__bf16>(dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, ntaps, q, s);
         else wgrad_tile_t<_Float16>(dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, ntaps, q, s);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, s, part, q.nslices, n, alpha, dw);

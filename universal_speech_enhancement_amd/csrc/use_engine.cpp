@@ -917,6 +917,7 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "conv_v7_max_units")) { conv_v7_set_max_units((long)value); return USE_OK; }
     if (!strcmp(name, "conv_v7_modes")) { conv_v7_set_modes((int)value); return USE_OK; }           // bit 0: plain, 1: residual, 2: fused shortcut
     if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
+    if (!strcmp(name, "wgrad_mfma16")) { wgrad_set_mfma16((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_blocks")) { wgrad_set_blocks((int)value); return USE_OK; }
     if (!strcmp(name, "conv_sk_max_px")) { conv_sk_set_max_px((long)value); return USE_OK; }             // 0: conv_sk off
 #ifdef USE_HIP_EXPERIMENTS
@@ -1793,14 +1794,14 @@ int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C
 }
 
 // ---- backward operators (fp32 NHWC device tensors; SURVEY 8f4 minimum slice: one res-block) ----
-size_t use_op_wgrad_workspace(int B, int H, int W, int Cout, int Cin, int ntaps) {
-    return (B < 1 || H < 1 || W < 1 || Cout < 1 || Cin < 1) ? 0 : wgrad_workspace_floats(B, H, W, Cout, Cin, ntaps == 1 ? 1 : 9);
+size_t use_op_wgrad_workspace(int B, int H, int W, int Cout, int Cin, int ntaps, int dtype) {
+    return (B < 1 || H < 1 || W < 1 || Cout < 1 || Cin < 1) ? 0 : wgrad_workspace_floats(B, H, W, Cout, Cin, ntaps == 1 ? 1 : 9, dtype);
 }
 int use_op_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,
                  float* work, size_t work_floats, use_stream_t stream) {
     if (!dy || !x || !dw || B < 1 || H < 1 || W < 1 || Cout < 1 || Cin < 1 || (ntaps != 1 && ntaps != 9)) return fail(USE_E_INVALID, "use_op_wgrad: bad argument");
     if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_F16) return fail(USE_E_INVALID, "use_op_wgrad: bad dtype");
-    if (work && work_floats < wgrad_workspace_floats(B, H, W, Cout, Cin, ntaps)) return fail(USE_E_INVALID, "use_op_wgrad: workspace too small");
+    if (work && work_floats < wgrad_workspace_floats(B, H, W, Cout, Cin, ntaps, dtype)) return fail(USE_E_INVALID, "use_op_wgrad: workspace too small");
     if (!launch_wgrad(dy, x, dtype, dw, db, B, H, W, Cout, Cin, ntaps, alpha, (work && work_floats) ? work : nullptr, (hipStream_t)stream))
         return fail(USE_E_INVALID, "use_op_wgrad: 16-bit inputs need the workspace and channel counts that are multiples of 4");
     HIPCHK(hipGetLastError());

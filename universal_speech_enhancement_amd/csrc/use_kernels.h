@@ -161,7 +161,8 @@ void launch_score_out(const float* pyr, int pc, const float* t, int t_stride, co
 
 // ---- backward kernels of one res-block (use_bwd.hip; fp32 storage, NHWC): the gradient half of train_step, minimum slice ----
 // work = nullptr: the 32 x 32-tile kernel with atomic slices; else wgrad_workspace_floats() floats of scratch for the tiled kernel
-size_t wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin, int ntaps);
+size_t wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin, int ntaps, int dtype);
+void wgrad_set_mfma16(int v);                 // 16-bit tensors: 1 (default) 16-bit MFMA kernel, 0 fp32 MFMA on converted operands
 void wgrad_set_blocks(int n);                 // target workgroup count of the tiled weight-gradient kernel (tiles x pixel slices)
 // dy / x in `dtype` (fp32 / bf16 / fp16 storage; converted while staging, exact-fp32 MFMA); false: case not served (16-bit without workspace)
 bool launch_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db, int B, int H, int W, int Cout, int Cin, int ntaps, float alpha,

@@ -85,7 +85,7 @@ def conv_wgrad(dy, x, ntaps=9, alpha=1.0, with_bias=True, tiled=True):
     dw = torch.empty(Cout, Cin, *((3, 3) if ntaps == 9 else ()), dtype=torch.float32, device=dy.device)
     db = torch.empty(Cout, dtype=torch.float32, device=dy.device) if with_bias else None
     lib = _lib.lib()
-    n = lib.use_op_wgrad_workspace(B, H, W, Cout, Cin, ntaps) if tiled else 0
+    n = lib.use_op_wgrad_workspace(B, H, W, Cout, Cin, ntaps, dtype_code(x)) if tiled else 0
     work = torch.empty(n, dtype=torch.float32, device=dy.device) if n else None
     check(lib.use_op_wgrad(_p(dy), _p(x), dtype_code(x), _p(dw), _p(db), B, H, W, Cout, Cin, ntaps, alpha, _p(work), n, _stream()), "use_op_wgrad")
     return dw, db
