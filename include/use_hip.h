@@ -226,7 +226,8 @@ int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C
  *                    work: use_op_wgrad_workspace(...) floats of scratch for the tiled kernel (per-slice partial tiles, summed without
  *                    atomics), or null for the small-tile kernel with atomic accumulation.
  * use_op_gn_act_bwd: gradient of act(GroupNorm(groups, eps)(x)) (act: 0 none, 1 SiLU) against dy: dx (+ add_scale * add when add is
- *                    given), dgamma, dbeta; `work`: use_op_gn_workspace(B, C, groups) floats of scratch, 8-byte aligned.
+ *                    given), dgamma, dbeta; `work`: use_op_gn_workspace(B, C, groups) floats of scratch, 8-byte aligned; have_stats != 0:
+ *                    `work` is the workspace use_op_gn_act_fwd ran in for the same x, whose statistics are reused.
  * use_op_gn_act_fwd: y = act(GroupNorm(x)) (the operand of the following convolution's weight gradient, recomputed); same workspace.
  * use_op_colsum:     out[b][c] = scale * sum_p x[b,p,c]            (the gradient reaching Dense_0's output)
  * use_op_dense_bwd:  Dense_0(SiLU(temb)): g [B][Cout] -> dW [Cout][K], db [Cout], dtemb [B][K].
@@ -236,7 +237,7 @@ int use_op_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db,
                  float* work, size_t work_floats, use_stream_t stream);
 size_t use_op_gn_workspace(int B, int C, int groups);
 int use_op_gn_act_bwd(const void* x, const void* dy, int dtype, const float* gamma, const float* beta, int groups, float eps, int act, const void* add,
-                      float add_scale, int B, int HW, int C, float* work, void* dx, float* dgamma, float* dbeta, use_stream_t stream);
+                      float add_scale, int B, int HW, int C, float* work, int have_stats, void* dx, float* dgamma, float* dbeta, use_stream_t stream);
 int use_op_gn_act_fwd(const void* x, int dtype, const float* gamma, const float* beta, int groups, float eps, int act, int B, int HW, int C, float* work,
                       void* y, use_stream_t stream);
 int use_op_colsum(const float* x, int B, int HW, int C, float scale, float* out, use_stream_t stream);

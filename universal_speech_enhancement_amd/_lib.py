@@ -96,7 +96,7 @@ SYMBOLS = {
     "use_op_wgrad_workspace": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i]),
     "use_op_wgrad": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, C.c_size_t, _vp]),
     "use_op_gn_workspace": (C.c_size_t, [_i, _i, _i]),
-    "use_op_gn_act_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _f, _i, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "use_op_gn_act_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _f, _i, _vp, _f, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "use_op_gn_act_fwd": (_i, [_vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     "use_op_colsum": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
     "use_op_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

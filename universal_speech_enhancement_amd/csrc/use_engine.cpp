@@ -1810,7 +1810,7 @@ int use_op_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db,
 // workspace of the two GroupNorm operators, in floats (8-byte aligned): [fp64 slice partials][mean, rstd][s1, s2][m1, m2]
 size_t use_op_gn_workspace(int B, int C, int groups) { return (B < 1 || C < 1 || groups < 1) ? 0 : gn_workspace_floats(B, C, groups); }
 int use_op_gn_act_bwd(const void* x, const void* dy, int dtype, const float* gamma, const float* beta, int groups, float eps, int act, const void* add,
-                      float add_scale, int B, int HW, int C, float* work, void* dx, float* dgamma, float* dbeta, use_stream_t stream) {
+                      float add_scale, int B, int HW, int C, float* work, int have_stats, void* dx, float* dgamma, float* dbeta, use_stream_t stream) {
     if (!x || !dy || !gamma || !beta || !work || !dx || !dgamma || !dbeta || groups < 1 || C % groups) return fail(USE_E_INVALID, "use_op_gn_act_bwd: bad argument");
     if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_F16) return fail(USE_E_INVALID, "use_op_gn_act_bwd: bad dtype");
     if ((uintptr_t)work % 8) return fail(USE_E_INVALID, "use_op_gn_act_bwd: workspace must be 8-byte aligned");
@@ -1818,7 +1818,8 @@ int use_op_gn_act_bwd(const void* x, const void* dy, int dtype, const float* gam
     double* part = (double*)work;
     float* mean = work + (size_t)4 * B * GN_MAX_SLICES * std::max(C, groups); float* rstd = mean + (size_t)B * groups;
     float* s1 = rstd + (size_t)B * groups; float* s2 = s1 + (size_t)B * C; float* m12 = s2 + (size_t)B * C;
-    if (!launch_gn_stats(x, dtype, B, HW, C, groups, eps, mean, rstd, part, s) ||
+    // have_stats: `work` is the workspace use_op_gn_act_fwd ran in for the same x - its mean / rstd are reused, one pass over x saved
+    if ((!have_stats && !launch_gn_stats(x, dtype, B, HW, C, groups, eps, mean, rstd, part, s)) ||
         !launch_gn_act_bwd(x, dy, dtype, mean, rstd, gamma, beta, act, add, add_scale, B, HW, C, groups, s1, s2, m12, part, dx, dgamma, dbeta, s))
         return fail(USE_E_INVALID, "use_op_gn_act_bwd: 16-bit tensors need C to be a multiple of 8 (and C / 8 <= 256)");
     HIPCHK(hipGetLastError());

@@ -32,7 +32,7 @@ from . import training_ops as ops
 SQRT1_2 = 0.70710678118654752440
 
 
-def _conv_dev(x, w, b, w_mode, ntaps, cout, scale=1.0, out_dtype=None):
+def _conv_dev(x, w, b, w_mode, ntaps, cout, scale=1.0, out_dtype=None, temb=None, res=None):
     """``use_op_conv_dev``: x [B,H,W,Cin] NHWC in fp32 / bf16 / fp16 storage (the MFMA operand type), w / b fp32 DEVICE parameter tensors
     (laid out in x's type on the device); the result in ``out_dtype`` (default: x's)."""
     B, H, W, Cin = x.shape
@@ -42,6 +42,8 @@ def _conv_dev(x, w, b, w_mode, ntaps, cout, scale=1.0, out_dtype=None):
     op.dtype, op.out_dtype = ops.dtype_code(x), ops.dtype_code(out)
     op.src0, op.w, op.bias = x.data_ptr(), w.data_ptr(), (b.data_ptr() if b is not None else None)
     op.out_scale, op.out = scale, out.data_ptr()
+    op.temb = temb.data_ptr() if temb is not None else None         # fp32 [B][cout], added per item before the scale
+    op.res = res.data_ptr() if res is not None else None            # out's type and shape, added before the scale
     lib = _lib.lib()
     n = lib.use_op_conv_dev_workspace(C.byref(op))
     work = torch.empty(n, dtype=torch.uint8, device=x.device)
@@ -51,32 +53,41 @@ def _conv_dev(x, w, b, w_mode, ntaps, cout, scale=1.0, out_dtype=None):
 
 
 class _Conv(torch.autograd.Function):
-    """y = conv(x, w) + b.  w: [Cout][Cin][3][3], [Cout][Cin][1][1] (reference conv3x3 / conv1x1, layerspp.py:31-34) or the NIN matrix
-    [Cin][Cout] (layers.py:639-650).  Channel counts are multiples of 32 (the caller zero-pads the 2/4/6-channel ends of the network)."""
+    """y = (conv(x, w) + b [+ temb[b]] [+ res]) * scale - the fused convolution of the res-block (layerspp.py:282-314: Dense_0's row added to
+    Conv_0's output, the shortcut added to Conv_1's and the sum scaled by 1/sqrt(2)).  w: [Cout][Cin][3][3], [Cout][Cin][1][1] (reference
+    conv3x3 / conv1x1, layerspp.py:31-34) or the NIN matrix [Cin][Cout] (layers.py:639-650).  Channel counts are multiples of 32 (the
+    caller zero-pads the 2/4/6-channel ends of the network).  temb: fp32 [B][Cout]; res: the output's shape and type."""
 
     @staticmethod
-    def forward(ctx, x, w, b, out_dtype=None):
+    def forward(ctx, x, w, b, out_dtype=None, temb=None, res=None, scale=1.0):
         x, w = x.contiguous(), w.contiguous()
         nin = w.dim() == 2
         ntaps = 1 if nin or w.shape[2] == 1 else 9
         cout = w.shape[1] if nin else w.shape[0]
         ctx.save_for_backward(x, w)
-        ctx.nin, ctx.ntaps, ctx.has_bias = nin, ntaps, b is not None
-        return _conv_dev(x, w, b, 2 if nin else 0, ntaps, cout, out_dtype=out_dtype)
+        ctx.nin, ctx.ntaps, ctx.has_bias, ctx.scale = nin, ntaps, b is not None, float(scale)
+        ctx.has_temb, ctx.res_dtype = temb is not None, (None if res is None else res.dtype)
+        return _conv_dev(x, w, b, 2 if nin else 0, ntaps, cout, scale=scale, out_dtype=out_dtype,
+                         temb=None if temb is None else temb.float().contiguous(), res=None if res is None else res.contiguous())
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
+        g_res = g_temb = None
+        if ctx.res_dtype is not None and ctx.needs_input_grad[5]:
+            g_res = (gy * ctx.scale).to(ctx.res_dtype)
+        if ctx.has_temb and ctx.needs_input_grad[4]:
+            g_temb = gy.sum((1, 2), dtype=torch.float32) * ctx.scale
         gy = gy.to(x.dtype).contiguous()            # the layer's operand type (the 2/4/6-channel ends of a 16-bit network change type)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             # NIN: dx = dy W^T, i.e. a 1x1 conv whose [cout][cin] weight is W itself; conv: the flipped, transposed weight (w_mode 1)
-            gx = _conv_dev(gy, w, None, 0 if ctx.nin else 1, ctx.ntaps, x.shape[3])
+            gx = _conv_dev(gy, w, None, 0 if ctx.nin else 1, ctx.ntaps, x.shape[3], scale=ctx.scale)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = ops.conv_wgrad(gy, x, ntaps=ctx.ntaps, with_bias=ctx.has_bias)
+            dw, db = ops.conv_wgrad(gy, x, ntaps=ctx.ntaps, alpha=ctx.scale, with_bias=ctx.has_bias)
             gw = dw.t().contiguous() if ctx.nin else dw.view(w.shape)
             gb = db
-        return gx, gw, gb, None
+        return gx, gw, gb, None, g_temb, g_res, None
 
 
 class _GNAct(torch.autograd.Function):
@@ -85,14 +96,15 @@ class _GNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, groups, act):
         x = x.contiguous()
-        ctx.save_for_backward(x, gamma, beta)
+        y, work = ops.gn_act_fwd(x, gamma, beta, groups, act=act, return_work=True)
+        ctx.save_for_backward(x, gamma, beta, work)     # the workspace holds mean / rstd: the backward does not recompute them
         ctx.groups, ctx.act = groups, act
-        return ops.gn_act_fwd(x, gamma, beta, groups, act=act)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, gamma, beta = ctx.saved_tensors
-        dx, dg, db = ops.gn_act_bwd(x, gy.contiguous(), gamma, beta, ctx.groups, act=ctx.act)
+        x, gamma, beta, work = ctx.saved_tensors
+        dx, dg, db = ops.gn_act_bwd(x, gy.contiguous(), gamma, beta, ctx.groups, act=ctx.act, fwd_work=work)
         return dx, dg, db, None, None
 
 
@@ -147,14 +159,12 @@ def _resblock(x, temb_act, P, p, up=False, down=False):
     h = _gn(x, P, p + ".GroupNorm_0", 1)
     if up or down:
         h, x = fir(h, up), fir(x, up)
-    h = conv(h, P[p + ".Conv_0.weight"], P[p + ".Conv_0.bias"])
-    if temb_act is not None:
-        h = h + F.linear(temb_act, P[p + ".Dense_0.weight"], P[p + ".Dense_0.bias"]).to(h.dtype)[:, None, None, :]
+    dense = None if temb_act is None else F.linear(temb_act, P[p + ".Dense_0.weight"], P[p + ".Dense_0.bias"])
+    h = conv(h, P[p + ".Conv_0.weight"], P[p + ".Conv_0.bias"], None, dense)               # + Dense_0(act(temb)) per item, in the epilogue
     h = _gn(h, P, p + ".GroupNorm_1", 1)
-    h = conv(h, P[p + ".Conv_1.weight"], P[p + ".Conv_1.bias"])
     if (p + ".Conv_2.weight") in P:
         x = conv(x, P[p + ".Conv_2.weight"], P[p + ".Conv_2.bias"])
-    return (x + h) * SQRT1_2
+    return conv(h, P[p + ".Conv_1.weight"], P[p + ".Conv_1.bias"], None, None, x, SQRT1_2)  # (shortcut + Conv_1(h)) / sqrt(2) in the epilogue
 
 
 def _attn_block(x, P, p):
@@ -163,7 +173,7 @@ def _attn_block(x, P, p):
     h = _gn(x, P, p + ".GroupNorm_0", 0)
     q, k, v = (conv(h, P[f"{p}.NIN_{i}.W"], P[f"{p}.NIN_{i}.b"]).view(B, H * W, Cc) for i in range(3))
     a = attn_core(q, k, v).view(B, H, W, Cc)
-    return (x + conv(a, P[p + ".NIN_3.W"], P[p + ".NIN_3.b"])) * SQRT1_2
+    return conv(a, P[p + ".NIN_3.W"], P[p + ".NIN_3.b"], None, None, x, SQRT1_2)
 
 
 def ncsnpp_forward_train(P: Dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, ch_mult: Sequence[int], num_res_blocks: int,

@@ -91,25 +91,26 @@ def conv_wgrad(dy, x, ntaps=9, alpha=1.0, with_bias=True, tiled=True):
     return dw, db
 
 
-def gn_act_bwd(x, dy, gamma, beta, groups, act=1, add=None, add_scale=1.0, eps=1e-6):
+def gn_act_bwd(x, dy, gamma, beta, groups, act=1, add=None, add_scale=1.0, eps=1e-6, fwd_work=None):
+    """``fwd_work``: the workspace ``gn_act_fwd(..., return_work=True)`` ran in for the same x - its statistics are reused."""
     B, H, W, Cc = x.shape
     assert dy.dtype == x.dtype and (add is None or add.dtype == x.dtype)
-    work = torch.empty(_lib.lib().use_op_gn_workspace(B, Cc, groups), dtype=torch.float32, device=x.device)
+    work = fwd_work if fwd_work is not None else torch.empty(_lib.lib().use_op_gn_workspace(B, Cc, groups), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     dg, dbt = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
     check(_lib.lib().use_op_gn_act_bwd(_p(x), _p(dy), dtype_code(x), _p(gamma), _p(beta), groups, eps, act, _p(add), add_scale, B, H * W, Cc,
-                                        _p(work), _p(dx), _p(dg), _p(dbt), _stream()), "use_op_gn_act_bwd")
+                                        _p(work), int(fwd_work is not None), _p(dx), _p(dg), _p(dbt), _stream()), "use_op_gn_act_bwd")
     return dx, dg, dbt
 
 
-def gn_act_fwd(x, gamma, beta, groups, act=1, eps=1e-6):
+def gn_act_fwd(x, gamma, beta, groups, act=1, eps=1e-6, return_work=False):
     """act(GroupNorm(x)) - the operand of the following convolution's weight gradient, recomputed from the stored pre-activation."""
     B, H, W, Cc = x.shape
     work = torch.empty(_lib.lib().use_op_gn_workspace(B, Cc, groups), dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
     check(_lib.lib().use_op_gn_act_fwd(_p(x), dtype_code(x), _p(gamma), _p(beta), groups, eps, act, B, H * W, Cc, _p(work), _p(y), _stream()),
           "use_op_gn_act_fwd")
-    return y
+    return (y, work) if return_work else y
 
 
 def fir(x, up):
