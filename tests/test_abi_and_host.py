@@ -247,3 +247,47 @@ def test_training_entry_points_refuse_without_a_tape_or_a_gpu():
     assert net.trainable
     with pytest.raises(_lib.UseHipError):
         net(torch.zeros(1, 2, 64, 64, dtype=torch.complex64), torch.ones(1))
+
+
+def test_module_is_a_lightning_module_where_lightning_exists(monkeypatch):
+    """The reference's SGMSEModule is a LightningModule (SGMSE_module.py:10): with `lightning` importable the stand-in subclasses it and
+    logs what the reference logs (train / val / test loss, lr); without it (this image) it is a plain nn.Module with the same methods."""
+    import importlib
+    import sys
+    import types
+    import torch
+    import universal_speech_enhancement_amd.SGMSE_module as M
+    assert not M.HAS_LIGHTNING and M.SGMSEModule.__mro__[1] is torch.nn.Module       # this image has no Lightning
+
+    class FakeLightningModule(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self._trainer, self.logged = None, []
+
+        def log(self, name, value, **kw):
+            self.logged.append((name, float(value), kw))
+
+        def optimizers(self):
+            return types.SimpleNamespace(param_groups=[{"lr": 5e-4}])
+
+    fake = types.ModuleType("lightning")
+    fake.LightningModule = FakeLightningModule
+    monkeypatch.setitem(sys.modules, "lightning", fake)
+    try:
+        L = importlib.reload(M)
+        assert L.HAS_LIGHTNING and issubclass(L.SGMSEModule, FakeLightningModule)
+        score = torch.nn.Module()
+        score.score_net = types.SimpleNamespace(trainable=True)
+        score.train_step = lambda batch: torch.tensor(3.5, requires_grad=True)
+        mod = L.SGMSEModule(Score=score)
+        assert float(mod.validation_step({}).detach()) == 3.5 and mod.logged == []          # no trainer attached: nothing is logged
+        mod._trainer = object()
+        loss = mod.training_step({}, 0)
+        assert loss.requires_grad
+        mod.validation_step({}); mod.test_step({})
+        assert [n for n, _, _ in mod.logged] == ["train/loss_Score", "lr", "val/loss_Score", "test/loss_Score"]
+        assert mod.logged[0][2] == dict(on_step=True, on_epoch=True, prog_bar=True) and mod.logged[1][1] == 5e-4
+    finally:
+        monkeypatch.delitem(sys.modules, "lightning")
+        importlib.reload(M)
+    assert not M.HAS_LIGHTNING

@@ -1,8 +1,9 @@
 """``GANModule`` with the constructor keys and ``predict_step`` contract of the reference's
 ``src/models/LSGAN_module.py:10-49,139-155`` -- the refine stage of the reference's documented pipeline (SGMSE sampler, then
-this) -- without the Lightning dependency: ``predict_step(batch, batch_idx)`` runs ``G(batch)``, trims every ``fake`` item
-to ``sample_length`` and writes it to ``audio_path.replace(data_folder, target_folder)``.  Only the generator is served;
-discriminator, criteria and optimisers are accepted and ignored (training is out of scope).
+this): ``predict_step(batch, batch_idx)`` runs ``G(batch)``, trims every ``fake`` item to ``sample_length`` and writes it to
+``audio_path.replace(data_folder, target_folder)``.  A ``lightning.LightningModule`` where Lightning is installed, a plain ``nn.Module``
+otherwise (as ``SGMSEModule``).  Only the generator is served; discriminator, criteria and optimisers are accepted and ignored (GAN
+training is out of scope).
 """
 from __future__ import annotations
 
@@ -11,10 +12,10 @@ import os
 import numpy as np
 import torch
 
-from .SGMSE_module import _write_wav
+from .SGMSE_module import _Base, _write_wav
 
 
-class GANModule(torch.nn.Module):
+class GANModule(_Base):
     def __init__(self, G: torch.nn.Module, D=None, G_optimizer=None, D_optimizer=None, G_scheduler=None, D_scheduler=None,
                  G_criterion=None, D_criterion=None, compile: bool = False, accumulate_grad_batches: int = 1,
                  rewrite_lr=False, G_lr=None, D_lr=None, wav_subtype: str = "PCM_16"):

@@ -1,7 +1,9 @@
-"""``SGMSEModule`` with the constructor and ``predict_step`` contract of the reference's
-``src/models/SGMSE_module.py:10-82`` -- without the Lightning dependency (absent on the target image): a plain
-``nn.Module`` whose ``predict_step(batch, batch_idx)`` runs ``Score.sample(batch)``, trims every item to
-``sample_length`` and writes it to ``audio_path.replace(data_folder, target_folder)``.
+"""``SGMSEModule`` with the constructor and step contract of the reference's ``src/models/SGMSE_module.py:10-82``:
+``predict_step(batch, batch_idx)`` runs ``Score.sample(batch)``, trims every item to ``sample_length`` and writes it to
+``audio_path.replace(data_folder, target_folder)``; ``training_step`` / ``validation_step`` / ``test_step`` /
+``configure_optimizers`` as there.  The base class is ``lightning.LightningModule`` where Lightning is installed (the reference's
+``Trainer.fit`` / ``Trainer.predict`` then drive it unchanged, with the ``self.log`` calls of the reference) and a plain ``nn.Module``
+where it is not (the target image) - the methods are the same either way.
 """
 from __future__ import annotations
 
@@ -20,7 +22,14 @@ def _write_wav(path: str, wav: np.ndarray, sr: int, subtype: str = "PCM_16"):
     write_wav(path, wav, int(sr), PCM16 if subtype == "PCM_16" else FLOAT32)
 
 
-class SGMSEModule(torch.nn.Module):
+try:                                                     # reference: class SGMSEModule(LightningModule), SGMSE_module.py:10
+    from lightning import LightningModule as _Base
+    HAS_LIGHTNING = True
+except Exception:                                        # not installed on the target image
+    _Base, HAS_LIGHTNING = torch.nn.Module, False
+
+
+class SGMSEModule(_Base):
     def __init__(self, Score: torch.nn.Module, optimizer=None, scheduler=None, compile: bool = False, sampler_kwargs=None,
                  wav_subtype: str = "PCM_16"):
         super().__init__()
@@ -57,15 +66,24 @@ class SGMSEModule(torch.nn.Module):
         """Reference :42-44."""
         return self.Score.train_step(batch)
 
+    def _log(self, name, value, **kw):
+        """``self.log`` of the reference's steps when a Lightning trainer is attached; nothing otherwise."""
+        if HAS_LIGHTNING and getattr(self, "_trainer", None) is not None:
+            self.log(name, value, **kw)
+
     @torch.no_grad()
     def validation_step(self, batch: dict, batch_idx: int = 0) -> torch.Tensor:
-        """Reference :56-58 (there the value goes to ``self.log("val/loss_Score", ...)``; without Lightning it is returned)."""
-        return self.get_score_loss(batch)
+        """Reference :56-58 (logs ``val/loss_Score``; the value is also returned)."""
+        loss = self.get_score_loss(batch)
+        self._log("val/loss_Score", loss, on_step=True, on_epoch=True, prog_bar=True)
+        return loss
 
     @torch.no_grad()
     def test_step(self, batch: dict, batch_idx: int = 0) -> torch.Tensor:
         """Reference :61-63."""
-        return self.get_score_loss(batch)
+        loss = self.get_score_loss(batch)
+        self._log("test/loss_Score", loss, on_step=True, on_epoch=True, prog_bar=True)
+        return loss
 
     def training_step(self, batch: dict, batch_idx: int = 0) -> torch.Tensor:
         """Reference :46-54 (there the value is also logged): the score-matching loss WITH its tape, for ``loss.backward()`` and an
@@ -75,7 +93,11 @@ class SGMSEModule(torch.nn.Module):
             raise RuntimeError("training_step: the score network's parameters are frozen - call Score.score_net.requires_grad_(True) "
                                "(validation_step / test_step give the loss without a tape)")
         with torch.enable_grad():
-            return self.get_score_loss(batch)
+            loss = self.get_score_loss(batch)
+        self._log("train/loss_Score", loss, on_step=True, on_epoch=True, prog_bar=True)
+        if HAS_LIGHTNING and getattr(self, "_trainer", None) is not None:       # reference :51-53: the learning rate, per epoch
+            self._log("lr", self.optimizers().param_groups[0]["lr"], on_step=False, on_epoch=True, prog_bar=True)
+        return loss
 
     def configure_optimizers(self):
         """Reference :26-40: ``optimizer(params=Score.parameters())`` and ``scheduler(optimizer=...)`` from the constructor's partials,
