@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const T* __restrict_
 // in the patch, i.e. an address offset - no alignment constraint.  Products of 16-bit values are exact in fp32: same numerics as the
 // fp32-MFMA kernel on the same data, up to the summation order.
 constexpr int WH_PITCH = 96;                                                     // LDS row pitch in elements (192 B)
-constexpr int WH_SMEM = (WG_PX + WG_PATCH) * WH_PITCH * 2 + WG_PX * 4;
+constexpr int WH_PATCH = 136;                                                    // largest halo patch: (RH, CW) = (32, 2); 8 x 8 chunks need 100
+constexpr int WH_SMEM = (WG_PX + WH_PATCH) * WH_PITCH * 2 + WG_PX * 4;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 template <typename T>
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const T* __restrict__ d
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* dyS = smem;                                                   // [64 px][pitch] T
     char* xS = dyS + WG_PX * WH_PITCH * 2;                              // [(RH + 2)(CW + 2) px][pitch] T
-    int* pofs = reinterpret_cast<int*>(xS + WG_PATCH * WH_PITCH * 2);   // patch pixel of chunk pixel j (centre tap); beyond the chunk: pixel 0's
+    int* pofs = reinterpret_cast<int*>(xS + WH_PATCH * WH_PITCH * 2);   // patch pixel of chunk pixel j (centre tap); beyond the chunk: pixel 0's
                                                                         // (always staged: dY is zero there, but 0 x stale LDS bits could be NaN)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hh = lane >> 5;
     const int tiles_ci = (Cin + WG_T - 1) / WG_T;
@@ -242,37 +243,60 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const T* __restrict__ d
     const bool want_b = bpart && ci0 == 0 && wn == 0;
     const int u_lo = blockIdx.y * q.per_slice, u_hi = min(u_lo + q.per_slice, q.units);
     const int rows_per_img = H / q.RH;
-    for (int u = u_lo; u < u_hi; ++u) {
+    // Register double buffering: the 16-byte pieces of chunk u + 1 (2 of dY, up to 5 of the patch per thread) are requested before the
+    // MFMAs of chunk u and stored to LDS after them, so their latency hides behind the 36 MFMAs (PMC of the synchronous form: waves
+    // waiting 0.61 of the time).
+    constexpr int NXP = NT == 9 ? (WH_PATCH * (WG_T / 8) + 255) / 256 : (WG_PX * (WG_T / 8)) / 256;
+    uint4 rdy[2], rx[NXP];
+    auto fetch = [&](int u) {
         const int cx = u % q.chunks_x, rr = u / q.chunks_x;
         const int b = rr / rows_per_img, y0 = (rr % rows_per_img) * q.RH, x0 = cx * q.CW;
-        __syncthreads();                                                // the previous chunk's MFMAs are done with the LDS
-        for (int e = t; e < WG_PX * (WG_T / 8); e += 256) {             // dY chunk, 16-byte pieces
-            const int j = e / (WG_T / 8), c8 = (e % (WG_T / 8)) * 8;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {                                // dY chunk
+            const int e = t + 256 * it, j = e / (WG_T / 8), c8 = (e % (WG_T / 8)) * 8;
             const int r = j / q.CW, cxx = x0 + j % q.CW;
-            if (j < nchunk && cxx < W && co0 + c8 < Cout) v = *reinterpret_cast<const uint4*>(dy + (((size_t)b * H + y0 + r) * W + cxx) * Cout + co0 + c8);
-            *reinterpret_cast<uint4*>(dyS + (j * WH_PITCH + c8) * 2) = v;
+            rdy[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (j < nchunk && cxx < W && co0 + c8 < Cout) rdy[it] = *reinterpret_cast<const uint4*>(dy + (((size_t)b * H + y0 + r) * W + cxx) * Cout + co0 + c8);
         }
-        if (NT == 9) {
-            for (int e = t; e < npatch * (WG_T / 8); e += 256) {        // X patch with a one-pixel halo, zero outside the image
-                const int pp = e / (WG_T / 8), c8 = (e % (WG_T / 8)) * 8;
+#pragma unroll
+        for (int it = 0; it < NXP; ++it) {
+            const int e = t + 256 * it, c8 = (e % (WG_T / 8)) * 8;
+            rx[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (NT == 9) {                                              // X patch with a one-pixel halo, zero outside the image
+                const int pp = e / (WG_T / 8);
                 const int yy = y0 + pp / PWp - 1, xx = x0 + pp % PWp - 1;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W && ci0 + c8 < Cin) v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + yy) * W + xx) * Cin + ci0 + c8);
-                *reinterpret_cast<uint4*>(xS + (pp * WH_PITCH + c8) * 2) = v;
-            }
-        } else {
-            for (int e = t; e < WG_PX * (WG_T / 8); e += 256) {         // 1x1: the chunk's own pixels at their patch positions
-                const int j = e / (WG_T / 8), c8 = (e % (WG_T / 8)) * 8;
-                const int r = j / q.CW, cxx = x0 + j % q.CW;
-                if (j < nchunk) {
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (cxx < W && ci0 + c8 < Cin) v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + y0 + r) * W + cxx) * Cin + ci0 + c8);
-                    *reinterpret_cast<uint4*>(xS + (((r + 1) * PWp + j % q.CW + 1) * WH_PITCH + c8) * 2) = v;
-                }
+                if (pp < npatch && yy >= 0 && yy < H && xx >= 0 && xx < W && ci0 + c8 < Cin)
+                    rx[it] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + yy) * W + xx) * Cin + ci0 + c8);
+            } else {                                                    // 1x1: the chunk's own pixels
+                const int j = e / (WG_T / 8), r = j / q.CW, cxx = x0 + j % q.CW;
+                if (j < nchunk && cxx < W && ci0 + c8 < Cin) rx[it] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + y0 + r) * W + cxx) * Cin + ci0 + c8);
             }
         }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = t + 256 * it, j = e / (WG_T / 8), c8 = (e % (WG_T / 8)) * 8;
+            *reinterpret_cast<uint4*>(dyS + (j * WH_PITCH + c8) * 2) = rdy[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NXP; ++it) {
+            const int e = t + 256 * it, c8 = (e % (WG_T / 8)) * 8;
+            if (NT == 9) {
+                const int pp = e / (WG_T / 8);
+                if (pp < npatch) *reinterpret_cast<uint4*>(xS + (pp * WH_PITCH + c8) * 2) = rx[it];
+            } else {                                                    // at their patch positions (pixels beyond the chunk: nowhere)
+                const int j = e / (WG_T / 8);
+                if (j < nchunk) *reinterpret_cast<uint4*>(xS + (((j / q.CW + 1) * PWp + j % q.CW + 1) * WH_PITCH + c8) * 2) = rx[it];
+            }
+        }
+    };
+    if (u_lo < u_hi) fetch(u_lo);
+    for (int u = u_lo; u < u_hi; ++u) {
+        __syncthreads();                                                // the previous chunk's MFMAs are done with the LDS
+        stash();
         __syncthreads();
+        if (u + 1 < u_hi) fetch(u + 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const typename Mfma<T>::frag a = ld_tr8<T>(dyS + aoff[ks][0], dyS + aoff[ks][1]);
@@ -724,11 +748,11 @@ void launch_attention_bwd(const float* q, const float* k, const float* v, const 
 }
 static int g_wgrad_blocks = 512;      // two workgroups per CU in one round (101 vs 105 ms per training step with 1024)
 void wgrad_set_blocks(int n) { g_wgrad_blocks = n > 0 ? n : 512; }
-static WgradPlan wgrad_plan(int B, int H, int W, int Cout, int Cin, int cw_max = WG_PX) {
+static WgradPlan wgrad_plan(int B, int H, int W, int Cout, int Cin, int cw_max = WG_PX, int max_patch = WG_PATCH) {
     WgradPlan q;
     q.CW = std::min(W, cw_max);
     q.RH = std::min(WG_PX / q.CW, H);
-    while (H % q.RH) --q.RH;                                          // a chunk stays inside one image
+    while (H % q.RH || (q.RH + 2) * (q.CW + 2) > max_patch) --q.RH;    // a chunk stays inside one image; the halo patch fits its buffer
     q.chunks_x = (W + q.CW - 1) / q.CW;
     q.units = B * (H / q.RH) * q.chunks_x;
     const int tiles = ((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T);
@@ -743,7 +767,7 @@ void wgrad_set_mfma16(int v) { g_wgrad_mfma16 = v; }
 static bool wgrad_use16(int dtype, int Cout, int Cin) { return dtype != DT_F32 && g_wgrad_mfma16 && Cout % 8 == 0 && Cin % 8 == 0; }
 size_t wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin, int ntaps, int dtype) {
     if (Cout % 4 || Cin % 4) return 0;
-    const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin, wgrad_use16(dtype, Cout, Cin) ? 8 : WG_PX);
+    const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin, wgrad_use16(dtype, Cout, Cin) ? 8 : WG_PX, wgrad_use16(dtype, Cout, Cin) ? WH_PATCH : WG_PATCH);
     return (size_t)q.nslices * ((size_t)Cout * Cin * ntaps + Cout);
 }
 template <typename T>
@@ -778,7 +802,7 @@ bool launch_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db
                   float* work, hipStream_t s) {
     if (work && Cout % 4 == 0 && Cin % 4 == 0) {
         const bool m16 = wgrad_use16(dtype, Cout, Cin);
-        const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin, m16 ? 8 : WG_PX);
+        const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin, m16 ? 8 : WG_PX, m16 ? WH_PATCH : WG_PATCH);
         const long n = (long)Cout * Cin * ntaps;
         float* part = work; float* bpart = work + (size_t)q.nslices * n;
         if (m16) {
