@@ -75,12 +75,12 @@ def test_training_step_gradients_match_the_reference_backward(golden_dir, tag):
     print(f"[measured] train grads {tag}: worst norm rel {worst_n:.3g}, worst tensor rel-to-max {worst_t:.3g}, {n_checked} tensors")
 
 
-@pytest.mark.parametrize("prec,tol_loss,tol_norm,tol_tensor", [("bf16", 5.2e-3, 2.6e-2, 0.22), ("fp16", 5e-5, 3.2e-3, 1.7e-2)])
+@pytest.mark.parametrize("prec,tol_loss,tol_norm,tol_tensor", [("bf16", 5.2e-3, 2.6e-2, 0.22), ("fp16", 5e-5, 4.5e-3, 2.7e-2)])
 def test_mixed_precision_gradients_stay_close_to_the_fp32_reference(golden_dir, prec, tol_loss, tol_norm, tol_tensor):
     """score_net.train_precision = "bf16" / "fp16": activations and their gradients in 16 bits, convolutions on the 16-bit MFMA kernels,
     parameters / weight gradients / statistics fp32 - against the reference's fp32 backward (case a).  Bounds about 2x the measured
     deviations (printed): bf16 loss 2.6e-3, gradient norms 1.3e-2, worst stored tensor 0.11 of its maximum (rms over all stored entries
-    7.1e-3); fp16 7e-6 / 1.6e-3 / 8.2e-3 (no loss scaling: the gradients of this loss sit well inside fp16's range)."""
+    7.5e-3); fp16 4e-6 / 2.3e-3 / 1.3e-2 (no loss scaling: the gradients of this loss sit well inside fp16's range)."""
     m, batch, t, z, start, g = _case(golden_dir, "a")
     m.score_net.requires_grad_(True)
     m.score_net.train_precision = prec

@@ -361,11 +361,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     }
 }
 
-template <bool ACT>
+// d/du [u sigmoid(u)].  FAST (16-bit storage): v_exp_f32 / v_rcp_f32 approximations, far below the 16-bit rounding of the result
+template <bool ACT, bool FAST = false>
 __device__ __forceinline__ float act_grad(float u) {
     if (!ACT) return 1.f;
-    const float sg = 1.0f / (1.0f + expf(-u));
-    return sg * (1.0f + u * (1.0f - sg));                    // d/du [u sigmoid(u)]
+    const float sg = FAST ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.44269504088896341f)) : 1.0f / (1.0f + expf(-u));
+    return sg * (1.0f + u * (1.0f - sg));
 }
 
 // s1[b][c] = sum_p du, s2[b][c] = sum_p du xhat; grid (channel blocks of 64, B), 256 threads = 4 pixel phases x 64 channels
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) void gn_act_bwd_part_kernel(const T* __restric
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float xh = (xs[k] - mu[k]) * rs[k];
-                const float du = ds[k] * act_grad<ACT>(fmaf(gm[k], xh, bt[k]));
+                const float du = ds[k] * act_grad<ACT, sizeof(T) == 2>(fmaf(gm[k], xh, bt[k]));
                 a1[k] += du; a2[k] = fmaf(du, xh, a2[k]);
             }
         }
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(256) void gn_act_bwd_applyv_kernel(const T* __restr
         for (int k = 0; k < VEC; ++k) {
             const int c = c4 + k, g = c / cpg;
             const float rs = rstd[b * G + g], xh = (xs[k] - mean[b * G + g]) * rs, gm = gamma[c];
-            const float du = ds[k] * act_grad<ACT>(fmaf(gm, xh, beta[c]));
+            const float du = ds[k] * act_grad<ACT, sizeof(T) == 2>(fmaf(gm, xh, beta[c]));
             o[k] = rs * (gm * du - m1[b * G + g] - xh * m2[b * G + g]);
             if (add) o[k] = fmaf(add_scale, as[k], o[k]);
         }
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256) void gn_act_fwdv_kernel(const T* __restrict__ 
         for (int k = 0; k < VEC; ++k) {
             const int c = c4 + k, g = c / cpg;
             const float u = fmaf(gamma[c], (xs[k] - mean[b * G + g]) * rstd[b * G + g], beta[c]);
-            o[k] = ACT ? u / (1.0f + expf(-u)) : u;
+            o[k] = ACT ? silu_f<sizeof(T) == 4>(u) : u;
         }
         Vec16<T>::store(y + (size_t)iv * VEC, o);
     }
