@@ -78,7 +78,14 @@ class _Conv(torch.autograd.Function):
             g_res = (gy * ctx.scale).to(ctx.res_dtype)
         if ctx.has_temb and ctx.needs_input_grad[4]:
             g_temb = gy.sum((1, 2), dtype=torch.float32) * ctx.scale
-        gy = gy.to(x.dtype).contiguous()            # the layer's operand type (the 2/4/6-channel ends of a 16-bit network change type)
+        # the 2/4/6-channel ends of a 16-bit network change type: the backward runs in the 16-bit one (fp32 input, 16-bit output: the
+        # weight gradient takes the input rounded to 16 bits - its products then run at the 16-bit MFMA rate; the input needs no gradient)
+        if gy.dtype != x.dtype:
+            if x.dtype == torch.float32 and not ctx.needs_input_grad[0]:
+                x = x.to(gy.dtype)
+            else:
+                gy = gy.to(x.dtype)
+        gy = gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             # NIN: dx = dy W^T, i.e. a 1x1 conv whose [cout][cin] weight is W itself; conv: the flipped, transposed weight (w_mode 1)
