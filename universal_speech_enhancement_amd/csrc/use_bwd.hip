@@ -331,12 +331,19 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const T* __restrict__ d
     }
 }
 
-// out[i] = alpha * sum over the slices of part[slice][i]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nslices, long n, float alpha, float* __restrict__ out) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+// out[i] = alpha * sum over the slices of part[slice][i]; the bias partials (nb entries per slice) ride along as elements n .. n + nb
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nslices, long n, float alpha, float* __restrict__ out,
+                                                           const float* __restrict__ bpart, int nb, float* __restrict__ bout) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n + nb; i += (long)gridDim.x * 256) {
         float a = 0.f;
-        for (int sl = 0; sl < nslices; ++sl) a += part[(size_t)sl * n + i];
-        out[i] = a * alpha;
+        if (i < n) {
+            for (int sl = 0; sl < nslices; ++sl) a += part[(size_t)sl * n + i];
+            out[i] = a * alpha;
+        } else {
+            const long c = i - n;
+            for (int sl = 0; sl < nslices; ++sl) a += bpart[(size_t)sl * nb + c];
+            bout[c] = a * alpha;
+        }
     }
 }
 
@@ -715,9 +722,12 @@ __global__ __launch_bounds__(128) void attn_bwd_cols_kernel(const float* __restr
 // i.e. w'[co][ci][tap] = W[ci][co][taps-1-tap];  mode 2: NIN matrix [cin][cout] (layers.py:639-650).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv_dev_kernel(const float* __restrict__ src, int mode, int cout, int cin, int ntaps, int cout_pad, int ck,
-                                                            T* __restrict__ dst, T* __restrict__ dstb) {
+                                                            T* __restrict__ dst, T* __restrict__ dstb, const float* __restrict__ bias,
+                                                            float* __restrict__ bias_out) {
     const long total = (long)ntaps * cout_pad * cin;
     constexpr int vec = 16 / (int)sizeof(T);
+    if (blockIdx.x == 0)                                                          // the zero-padded bias rides along
+        for (int i = threadIdx.x; i < cout_pad; i += 256) bias_out[i] = (bias && i < cout) ? bias[i] : 0.f;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int ci = (int)(idx % cin);
         const int tap = (int)((idx / cin) % ntaps);
@@ -734,10 +744,6 @@ __global__ __launch_bounds__(256) void pack_conv_dev_kernel(const float* __restr
             dstb[(((size_t)tap * (cin / ck) + ci / ck) * cout_pad + co) * ck + (((e / vec) ^ ((co >> 2) & 3)) * vec + e % vec)] = o;
         }
     }
-}
-__global__ __launch_bounds__(256) void pad_bias_kernel(const float* __restrict__ b, int cout, int cout_pad, float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < cout_pad) out[i] = (b && i < cout) ? b[i] : 0.f;
 }
 
 // ---- launch wrappers ------------------------------------------------------------------------------------------------------------
@@ -812,8 +818,8 @@ bool launch_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db
         } else if (dtype == DT_F32) wgrad_tile_t<float>(dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, ntaps, q, s);
         else if (dtype == DT_BF16) wgrad_tile_t<__bf16>(dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, ntaps, q, s);
         else wgrad_tile_t<_Float16>(dy, x, part, db ? bpart : nullptr, B, H, W, Cout, Cin, ntaps, q, s);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, s, part, q.nslices, n, alpha, dw);
-        if (db) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, bpart, q.nslices, (long)Cout, alpha, db);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((n + Cout + 255) / 256, 4096)), dim3(256), 0, s, part, q.nslices, n, alpha, dw,
+                           bpart, db ? Cout : 0, db);
         return true;
     }
     if (dtype != DT_F32) return false;
@@ -927,10 +933,9 @@ void launch_pack_conv_dev(const float* src, int mode, int cout, int cin, int nta
                           const float* bias, float* bias_out, hipStream_t s) {
     const long total = (long)ntaps * cout_pad * cin;
     const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 8192);
-    if (dtype == DT_F32)       hipLaunchKernelGGL(pack_conv_dev_kernel<float>, dim3(blocks), dim3(256), 0, s, src, mode, cout, cin, ntaps, cout_pad, dstb ? ck : 0, (float*)dst, (float*)dstb);
-    else if (dtype == DT_BF16) hipLaunchKernelGGL(pack_conv_dev_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, src, mode, cout, cin, ntaps, cout_pad, dstb ? ck : 0, (__bf16*)dst, (__bf16*)dstb);
-    else                       hipLaunchKernelGGL(pack_conv_dev_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, src, mode, cout, cin, ntaps, cout_pad, dstb ? ck : 0, (_Float16*)dst, (_Float16*)dstb);
-    hipLaunchKernelGGL(pad_bias_kernel, dim3((cout_pad + 255) / 256), dim3(256), 0, s, bias, cout, cout_pad, bias_out);
+    if (dtype == DT_F32)       hipLaunchKernelGGL(pack_conv_dev_kernel<float>, dim3(blocks), dim3(256), 0, s, src, mode, cout, cin, ntaps, cout_pad, dstb ? ck : 0, (float*)dst, (float*)dstb, bias, bias_out);
+    else if (dtype == DT_BF16) hipLaunchKernelGGL(pack_conv_dev_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, src, mode, cout, cin, ntaps, cout_pad, dstb ? ck : 0, (__bf16*)dst, (__bf16*)dstb, bias, bias_out);
+    else                       hipLaunchKernelGGL(pack_conv_dev_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, src, mode, cout, cin, ntaps, cout_pad, dstb ? ck : 0, (_Float16*)dst, (_Float16*)dstb, bias, bias_out);
 }
 
 }  // namespace use
