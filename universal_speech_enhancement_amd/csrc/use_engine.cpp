@@ -1621,6 +1621,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             case 4: if (!a.wb || (XC && !a.w2b)) return -1; launch_conv_v4(a, 0); return 0;
             case 8: if (!conv_v7_supports(a)) return -1; conv_v7_prepare(a.Cout, a.in_dtype); launch_conv_v7(a, 0); return 0;
 #ifdef USE_HIP_EXPERIMENTS
+            case 9: if (!conv_v8_supports(a)) return -1; launch_conv_v8(a, 0); return 0;      // (the weight copy is built on the first call)
             case 5: if (!a.wb || (XC && !a.w2b) || dt == DT_F32) return -1; launch_conv_v5(a, 0); return 0;
             case 6: if (!conv_v6_eligible(a)) return -1; launch_conv_v6(a, 0); return 0;
 #endif
@@ -1672,6 +1673,9 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             stats_host[i] = (float)((double)hs[i] / 1048576.0); stats_host[i + 1] = (float)((double)hs[i + 1] / 1048576.0);
         }
     }
+#ifdef USE_HIP_EXPERIMENTS
+    conv_v8_clear();                                          // its weight copies are keyed by the device pointers freed below
+#endif
     cleanup();
     return rc;
 }

@@ -83,7 +83,15 @@ bool conv_sk_eligible(const ConvArgs& a);
 void conv_sk_set_max_px(long n);                         // largest map (H*W) it is used for (default 16x20)
 void launch_conv_sk(const ConvArgs& a, hipStream_t s);
 void launch_conv_generic(const ConvArgs& a, hipStream_t s);   // conv_kernel / pyr_conv_kernel / conv_in_kernel only (no specialised schedule)
-void pyr_conv_set_pipe(int n);                           // pyramid-head convolution: workgroups per item of the pipelined form (0: off)
+void pyr_conv_set_pipe(int n);
+// (EXPERIMENTS build only) two-workgroups-per-CU form of the large-map 3x3 convolution (scripts/experiments/use_conv_v8.hip)
+bool conv_v8_supports(const ConvArgs& a);
+bool conv_v8_eligible(const ConvArgs& a);
+void conv_v8_prepare(const ConvArgs& a, hipStream_t s);      // builds the layer's chunk-major weight copy (never inside a stream capture)
+void launch_conv_v8(const ConvArgs& a, hipStream_t s);
+void conv_v8_set(int on);
+void conv_v8_set_min_blocks(long n);
+void conv_v8_clear();                           // pyramid-head convolution: workgroups per item of the pipelined form (0: off)
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 128 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);
