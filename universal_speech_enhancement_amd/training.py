@@ -1,18 +1,19 @@
 """Differentiable NCSN++ forward on the HIP operators: the network half of ``ScoreModel.train_step`` with gradients (SURVEY section 8
 row f4; reference ``model_wrapper.py:147-208`` driven by ``SGMSEModule.training_step``, ``SGMSE_module.py:46-54``).
 
-Every heavy operator of the network is one ``torch.autograd.Function`` whose forward AND backward are kernels of libuse_hip.so on fp32
-NHWC device tensors:
+Every heavy operator of the network is one ``torch.autograd.Function`` whose forward AND backward are kernels of libuse_hip.so on
+NHWC device tensors (fp32 as the reference trains, or 16-bit storage with fp32 parameters: ``compute_dtype``):
 
-* ``conv``      - forward ``use_op_conv_dev`` (implicit-GEMM MFMA kernel; the fp32 parameter tensor is laid out on the device each call,
-                  it changes every optimiser step); data gradient = the same kernel on the flipped / transposed weight (w_mode 1);
-                  weight and bias gradients ``use_op_wgrad``.  3x3, 1x1 and NIN ([Cin][Cout]) weights.
+* ``conv``      - forward ``use_op_conv_dev`` (implicit-GEMM MFMA kernel with the res-block's epilogue: + Dense_0 row, + shortcut, x 1/sqrt(2);
+                  the fp32 parameter tensor is laid out on the device each call, it changes every optimiser step); data gradient = the
+                  same kernel on the flipped / transposed weight (w_mode 1); weight and bias gradients ``use_op_wgrad`` (exact-fp32 MFMA
+                  for fp32 tensors, 16-bit MFMA for 16-bit ones).  3x3, 1x1 and NIN ([Cin][Cout]) weights.
 * ``gn_act``    - ``use_op_gn_act_fwd`` / ``use_op_gn_act_bwd`` (GroupNorm with or without SiLU).
 * ``fir``       - ``use_op_fir``; the x2 FIR resamplers are mutual transposes up to the gain.
 * ``attn_core`` - ``use_op_attention`` / ``use_op_attention_bwd``.
 
-torch's autograd records the tape and runs the glue between them (residual adds, channel concatenation, the [B, 512] time-embedding MLP
-and the Dense_0 projections - library GEMMs on a handful of rows).  The network structure follows the reference's ``NCSNpp.forward``
+torch's autograd records the tape and runs the glue between them (channel concatenation, the pyramid sums, the [B, 512] time-embedding
+MLP and the Dense_0 projections - library GEMMs on a handful of rows).  The network structure follows the reference's ``NCSNpp.forward``
 (``sgmse/backbones/ncsnpp.py:324-501``) for the configuration family of the predict path, with parameters addressed by the reference's
 state-dict names.  There is no CPU implementation: without libuse_hip.so / a GPU the first operator raises.
 """
