@@ -74,12 +74,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy
 
 // ---- weight gradient, tiled form ---------------------------------------------------------------------------------------------------
 // One workgroup = a 64 co x 64 ci tile of dW for ALL taps (4 waves as 2 x 2, each 32 x 32 x taps accumulators: 144 registers for a 3x3)
-// over one slice of the pixels.  Pixels are walked in chunks of RH rows x CW columns (RH CW <= 64, RH | H so that a chunk stays inside one
-// image): the chunk of dY ([64 px][64 co]) and the (RH + 2) x (CW + 2) halo patch of X ([px][64 ci], zero outside the image) are staged in
+// over one slice of the pixels.  Pixels are walked in chunks of RH rows x CW columns (8 x 8 where the map allows, RH | H so that a chunk stays
+// inside one image): the chunk of dY ([64 px][64 co]) and the (RH + 2) x (CW + 2) halo patch of X ([px][64 ci], zero outside the image) are staged in
 // LDS once and feed 9 MFMAs (one per tap: the same dY operand against the patch shifted by the tap) per pixel pair -
 // v_mfma_f32_32x32x2_f32, exact fp32.  Slices write their tile to part[slice][co][ci][tap] (the reference's weight layout);
 // wgrad_reduce_kernel sums the slices (deterministic: no atomics).  Two workgroups per CU overlap each other's staging.
-constexpr int WG_PX = 64, WG_T = 64, WG_PATCH = 198;          // pixels per chunk, tile edge, largest patch (RH, CW) = (1, 64) or (64, 1)
+constexpr int WG_PX = 64, WG_T = 64;                           // pixels per chunk, tile edge
+constexpr int WH_PATCH = 136;                                  // largest halo patch: (RH, CW) = (32, 2); 8 x 8 chunks need 100
+constexpr int WG_PATCH = 112;                                  // fp32-MFMA kernel: (RH, CW) = (16, 4) -> 108; 7 float4 of prefetch per thread
 constexpr int WG_SMEM = (WG_PX * WG_T + WG_PATCH * WG_T) * 4 + WG_PX * 4;
 
 struct WgradPlan { int RH, CW, chunks_x, units, per_slice, nslices; };
@@ -118,37 +120,62 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const T* __restrict_
     float bsum = 0.f;
     const int u_lo = blockIdx.y * q.per_slice, u_hi = min(u_lo + q.per_slice, q.units);
     const int rows_per_img = H / q.RH;
-    for (int u = u_lo; u < u_hi; ++u) {
+    // Register double buffering (as wgrad16_kernel): the float4 pieces of chunk u + 1 (4 of dY, up to 7 of the patch per thread) are
+    // requested before the 288 MFMAs of chunk u and stored to LDS after them.  The synchronous form ran at 0.56 of the fp32 MFMA rate
+    // with the clock at 2.39 GHz and 1.06 kW: its load -> barrier -> MFMA cycle was the limit, not power or memory.
+    constexpr int NDP = WG_PX * (WG_T / 4) / 256;                                            // 4
+    constexpr int NXP = NT == 9 ? (WG_PATCH * (WG_T / 4) + 255) / 256 : NDP;                  // 7 | 4
+    float4 rdy[NDP], rx[NXP];
+    auto fetch = [&](int u) __attribute__((always_inline)) {
         const int cx = u % q.chunks_x, rr = u / q.chunks_x;             // column chunk, row chunk (over all images)
         const int b = rr / rows_per_img, y0 = (rr % rows_per_img) * q.RH, x0 = cx * q.CW;
-        __syncthreads();                                                // the previous chunk's MFMAs are done with the LDS
-        for (int e = t; e < WG_PX * (WG_T / 4); e += 256) {             // dY chunk
-            const int j = e / (WG_T / 4), c4 = (e % (WG_T / 4)) * 4;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < NDP; ++it) {                              // dY chunk
+            const int e = t + 256 * it, j = e / (WG_T / 4), c4 = (e % (WG_T / 4)) * 4;
             const int r = j / q.CW, cxx = x0 + j % q.CW;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (j < nchunk && cxx < W && co0 + c4 < Cout) wg_ld4<T>(dy + (((size_t)b * H + y0 + r) * W + cxx) * Cout + co0 + c4, v);
-            *reinterpret_cast<float4*>(dyS + j * WG_T + c4) = make_float4(v[0], v[1], v[2], v[3]);
+            rdy[it] = make_float4(v[0], v[1], v[2], v[3]);
         }
-        if (NT == 9) {
-            for (int e = t; e < npatch * (WG_T / 4); e += 256) {        // X patch with a one-pixel halo, zero outside the image
-                const int pp = e / (WG_T / 4), c4 = (e % (WG_T / 4)) * 4;
+#pragma unroll
+        for (int it = 0; it < NXP; ++it) {
+            const int e = t + 256 * it, c4 = (e % (WG_T / 4)) * 4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (NT == 9) {                                              // X patch with a one-pixel halo, zero outside the image
+                const int pp = e / (WG_T / 4);
                 const int yy = y0 + pp / PWp - 1, xx = x0 + pp % PWp - 1;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W && ci0 + c4 < Cin) wg_ld4<T>(x + (((size_t)b * H + yy) * W + xx) * Cin + ci0 + c4, v);
-                *reinterpret_cast<float4*>(xS + pp * WG_T + c4) = make_float4(v[0], v[1], v[2], v[3]);
+                if (pp < npatch && yy >= 0 && yy < H && xx >= 0 && xx < W && ci0 + c4 < Cin) wg_ld4<T>(x + (((size_t)b * H + yy) * W + xx) * Cin + ci0 + c4, v);
+            } else {                                                    // 1x1: the chunk's own pixels
+                const int j = e / (WG_T / 4), r = j / q.CW, cxx = x0 + j % q.CW;
+                if (j < nchunk && cxx < W && ci0 + c4 < Cin) wg_ld4<T>(x + (((size_t)b * H + y0 + r) * W + cxx) * Cin + ci0 + c4, v);
             }
-        } else {
-            for (int e = t; e < WG_PX * (WG_T / 4); e += 256) {         // 1x1: the chunk's own pixels, stored at their patch positions
-                const int j = e / (WG_T / 4), c4 = (e % (WG_T / 4)) * 4;
-                const int r = j / q.CW, cxx = x0 + j % q.CW;
-                if (j < nchunk) {
-                    float v[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (cxx < W && ci0 + c4 < Cin) wg_ld4<T>(x + (((size_t)b * H + y0 + r) * W + cxx) * Cin + ci0 + c4, v);
-                    *reinterpret_cast<float4*>(xS + ((r + 1) * PWp + j % q.CW + 1) * WG_T + c4) = make_float4(v[0], v[1], v[2], v[3]);
-                }
+            rx[it] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < NDP; ++it) {
+            const int e = t + 256 * it, j = e / (WG_T / 4), c4 = (e % (WG_T / 4)) * 4;
+            *reinterpret_cast<float4*>(dyS + j * WG_T + c4) = rdy[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NXP; ++it) {
+            const int e = t + 256 * it, c4 = (e % (WG_T / 4)) * 4;
+            if (NT == 9) {
+                const int pp = e / (WG_T / 4);
+                if (pp < npatch) *reinterpret_cast<float4*>(xS + pp * WG_T + c4) = rx[it];
+            } else {                                                    // at their patch positions (pixels beyond the chunk: nowhere)
+                const int j = e / (WG_T / 4);
+                if (j < nchunk) *reinterpret_cast<float4*>(xS + ((j / q.CW + 1) * PWp + j % q.CW + 1) * WG_T + c4) = rx[it];
             }
         }
+    };
+    if (u_lo < u_hi) fetch(u_lo);
+    for (int u = u_lo; u < u_hi; ++u) {
+        __syncthreads();                                                // the previous chunk's MFMAs are done with the LDS
+        stash();
         __syncthreads();
+        if (u + 1 < u_hi) fetch(u + 1);
         const float* aP = dyS + wm * 32 + l31;
         const float* bP = xS + wn * 32 + l31;
 #pragma unroll 4
@@ -195,7 +222,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const T* __restrict_
 // in the patch, i.e. an address offset - no alignment constraint.  Products of 16-bit values are exact in fp32: same numerics as the
 // fp32-MFMA kernel on the same data, up to the summation order.
 constexpr int WH_PITCH = 96;                                                     // LDS row pitch in elements (192 B)
-constexpr int WH_PATCH = 136;                                                    // largest halo patch: (RH, CW) = (32, 2); 8 x 8 chunks need 100
 constexpr int WH_SMEM = (WG_PX + WH_PATCH) * WH_PITCH * 2 + WG_PX * 4;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -755,7 +781,7 @@ void launch_attention_bwd(const float* q, const float* k, const float* v, const 
 }
 static int g_wgrad_blocks = 512;      // two workgroups per CU in one round (101 vs 105 ms per training step with 1024)
 void wgrad_set_blocks(int n) { g_wgrad_blocks = n > 0 ? n : 512; }
-static WgradPlan wgrad_plan(int B, int H, int W, int Cout, int Cin, int cw_max = WG_PX, int max_patch = WG_PATCH) {
+static WgradPlan wgrad_plan(int B, int H, int W, int Cout, int Cin, int cw_max = 8, int max_patch = WH_PATCH) {
     WgradPlan q;
     q.CW = std::min(W, cw_max);
     q.RH = std::min(WG_PX / q.CW, H);
@@ -774,7 +800,7 @@ void wgrad_set_mfma16(int v) { g_wgrad_mfma16 = v; }
 static bool wgrad_use16(int dtype, int Cout, int Cin) { return dtype != DT_F32 && g_wgrad_mfma16 && Cout % 8 == 0 && Cin % 8 == 0; }
 size_t wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin, int ntaps, int dtype) {
     if (Cout % 4 || Cin % 4) return 0;
-    const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin, wgrad_use16(dtype, Cout, Cin) ? 8 : WG_PX, wgrad_use16(dtype, Cout, Cin) ? WH_PATCH : WG_PATCH);
+    const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin, 8, wgrad_use16(dtype, Cout, Cin) ? WH_PATCH : WG_PATCH);
     return (size_t)q.nslices * ((size_t)Cout * Cin * ntaps + Cout);
 }
 template <typename T>
@@ -809,7 +835,7 @@ bool launch_wgrad(const void* dy, const void* x, int dtype, float* dw, float* db
                   float* work, hipStream_t s) {
     if (work && Cout % 4 == 0 && Cin % 4 == 0) {
         const bool m16 = wgrad_use16(dtype, Cout, Cin);
-        const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin, m16 ? 8 : WG_PX, m16 ? WH_PATCH : WG_PATCH);
+        const WgradPlan q = wgrad_plan(B, H, W, Cout, Cin, 8, m16 ? WH_PATCH : WG_PATCH);
         const long n = (long)Cout * Cin * ntaps;
         float* part = work; float* bpart = work + (size_t)q.nslices * n;
         if (m16) {
