@@ -218,3 +218,43 @@ def test_attention_block_matches_the_reference(golden_dir, dt, tol):
     err = _rel(_nchw(y, Cc), torch.from_numpy(g["y"]))
     print(f"attn dtype {dt}: {err:.3g}")
     assert err < tol, err
+
+
+@pytest.mark.parametrize("dt", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(2, 16, 32, 64, 128, 9), (1, 8, 8, 96, 32, 9), (2, 12, 10, 32, 64, 1), (1, 32, 64, 128, 128, 9)])
+def test_conv_with_device_weights_equals_conv_with_host_packed_weights(dt, shape):
+    """use_op_conv_dev (training path: fp32 parameter tensors in HBM, laid out for the kernels on the device) against use_op_conv (host
+    packing) - bit-identical in every storage type; w_mode 1 = the data gradient's operand (flipped, transposed), w_mode 2 = NIN."""
+    from universal_speech_enhancement_amd import training as TR
+    from universal_speech_enhancement_amd import training_ops as T
+    B, H, W, Cin, Cout, ntaps = shape
+    g = torch.Generator().manual_seed(Cin * 7 + H)
+    x = torch.randn(B, H, W, Cin, generator=g).to(TD[dt]).cuda()
+    w = torch.randn(Cout, Cin, *((3, 3) if ntaps == 9 else (1, 1)), generator=g) * 0.1
+    b = torch.randn(Cout, generator=g) * 0.1
+
+    def host(xx, ww, bb, nt):
+        Bn, Hn, Wn, Ci = xx.shape
+        Co = ww.shape[0]
+        out = torch.empty(Bn, Hn, Wn, Co, dtype=xx.dtype, device="cuda")
+        op = UseConvOp()
+        op.B, op.H, op.W, op.C0, op.C1, op.Cout, op.ntaps, op.act, op.dtype, op.out_dtype, op.variant = Bn, Hn, Wn, Ci, 0, Co, nt, 0, dt, dt, 0
+        op.src0 = xx.data_ptr()
+        wn = np.ascontiguousarray(ww.numpy(), dtype=np.float32); op.w = wn.ctypes.data
+        bn = None
+        if bb is not None:
+            bn = np.ascontiguousarray(bb.numpy(), dtype=np.float32); op.bias = bn.ctypes.data
+        op.out_scale, op.out = 1.0, out.data_ptr()
+        check(_lib.lib().use_op_conv(C.byref(op), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "use_op_conv")
+        return out
+
+    got = TR._conv_dev(x, w.cuda(), b.cuda(), 0, ntaps, Cout)
+    torch.cuda.synchronize()
+    assert torch.equal(got, host(x, w.reshape(Cout, Cin, *w.shape[2:]) if ntaps == 9 else w.reshape(Cout, Cin), b, ntaps))
+    gy = torch.randn(B, H, W, Cout, generator=g).to(TD[dt]).cuda()              # data gradient: w_mode 1 vs the host-built operand
+    gx = TR._conv_dev(gy, w.cuda(), None, 1, ntaps, Cin)
+    wt = torch.flip(w, (2, 3)).transpose(0, 1).contiguous()
+    assert torch.equal(gx, host(gy, wt if ntaps == 9 else wt.reshape(Cin, Cout), None, ntaps))
+    if ntaps == 1:                                                               # NIN matrix [Cin][Cout]
+        Wn = w.reshape(Cout, Cin).t().contiguous()
+        assert torch.equal(TR._conv_dev(x, Wn.cuda(), b.cuda(), 2, 1, Cout), got)
