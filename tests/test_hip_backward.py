@@ -142,3 +142,35 @@ def test_weight_gradient_on_the_16bit_matrix_pipe(dt, B, H, W, Cout, Cin, ntaps)
     refb = dyd.sum((0, 1, 2)) * 0.75
     assert float((db16.double().cpu() - refb).abs().max()) < 2e-6 * float(refb.abs().max()) + 1e-6
     assert float((db16 - db32).abs().max()) < 2e-6 * float(refb.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1.2e-2), (torch.float16, 1.5e-3)])
+@pytest.mark.parametrize("B,H,W,Cc,G,act", [(2, 12, 10, 32, 8, 1), (1, 64, 64, 128, 32, 1), (2, 4, 1, 256, 32, 0), (1, 8, 8, 96, 24, 1), (3, 16, 32, 384, 32, 1)])
+def test_groupnorm_silu_operators_in_every_storage_type(dt, tol, B, H, W, Cc, G, act):
+    """use_op_gn_act_fwd / use_op_gn_act_bwd (sliced reductions, statistics reused from the forward workspace, fused `add`) against
+    torch's autograd on the same (already rounded) tensors in fp64; 16-bit bounds = one storage rounding of the result."""
+    from universal_speech_enhancement_amd import training_ops as T
+    g = torch.Generator().manual_seed(B * 100 + Cc)
+    x = (torch.randn(B, H, W, Cc, generator=g) * 1.5 + 0.3).to(dt)
+    dy = torch.randn(B, H, W, Cc, generator=g).to(dt)
+    add = torch.randn(B, H, W, Cc, generator=g).to(dt)
+    gamma, beta = torch.randn(Cc, generator=g) * 0.5 + 1.0, torch.randn(Cc, generator=g) * 0.2
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = torch.nn.functional.group_norm(xr, G, gr, br, eps=1e-6)
+    if act:
+        yr = torch.nn.functional.silu(yr)
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    y, work = T.gn_act_fwd(x.cuda(), gamma.cuda(), beta.cuda(), G, act=act, return_work=True)
+    dx, dg, db = T.gn_act_bwd(x.cuda(), dy.cuda(), gamma.cuda(), beta.cuda(), G, act=act, add=add.cuda(), add_scale=0.5, fwd_work=work)
+    dx2, dg2, db2 = T.gn_act_bwd(x.cuda(), dy.cuda(), gamma.cuda(), beta.cuda(), G, act=act)      # statistics recomputed, no add
+    torch.cuda.synchronize()
+
+    def rel(a, b_):
+        return float((a.double().cpu() - b_).abs().max()) / float(b_.abs().max())
+    want_dx = xr.grad.permute(0, 2, 3, 1)
+    assert rel(y, yr.detach().permute(0, 2, 3, 1)) < tol
+    assert rel(dx2, want_dx) < tol
+    assert rel(dx, want_dx + 0.5 * add.double()) < tol
+    assert rel(dg, gr.grad) < max(tol * 0.1, 2e-6) and rel(db, br.grad) < max(tol * 0.1, 2e-6)     # parameter gradients: fp32 sums of fp32 terms
+    assert torch.equal(dg, dg2) and torch.equal(db, db2)
