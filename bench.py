@@ -182,9 +182,13 @@ def main():
         if Hm * Wm < 256 * 320:                                     # the smaller maps are hidden behind the other sub-batch's convolutions
             continue
         by = sum(b for b, _ in v) / len(v); ms = sum(m for _, m in v) / len(v)
+        # what actually binds the kernel: the fused GroupNorm + SiLU costs two quarter-rate transcendentals per
+        # staged element, which puts the FIR down-sampler (each input evaluated 2.25x) and the pyramid heads above their HBM time
+        binds = {"fir_down": "valu (fused SiLU: v_exp + v_rcp per element, 2.25x redundant)", "pyr_conv": "valu (fused SiLU on a 1.4x halo) + mfma",
+                 "conv_in": "hbm write + GroupNorm atomics", "fir_up": "hbm"}.get(name, "hbm")
         hbm_kernels.append({"kernel": name, "map": f"{Hm}x{Wm}", "launches_per_score": len(v), "algorithmic_bytes": round(by),
                             "avg_ms": round(ms, 4), "achieved_GBps": round(by / (ms * 1e-3) / 1e9, 1),
-                            "frac": round(by / (ms * 1e-3) / (PEAK_HBM_TBPS * 1e12), 4)})
+                            "frac": round(by / (ms * 1e-3) / (PEAK_HBM_TBPS * 1e12), 4), "binds": binds})
     peak = PEAK_FP32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS      # bf16 and fp16 MFMA share the dense peak
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
     # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), which cannot be
