@@ -84,7 +84,15 @@ constexpr int WH_PATCH = 136;                                  // largest halo p
 constexpr int WG_PATCH = 112;                                  // fp32-MFMA kernel: (RH, CW) = (16, 4) -> 108; 7 float4 of prefetch per thread
 constexpr int WG_SMEM = (WG_PX * WG_T + WG_PATCH * WG_T) * 4 + WG_PX * 4;
 
-struct WgradPlan { int RH, CW, chunks_x, units, per_slice, nslices; };
+struct WgradPlan { int RH, CW, chunks_x, units, per_slice, nslices, tiles; };
+// workgroup -> (tile of dW, pixel slice).  Workgroups go to the 8 XCDs round-robin by their linear id, and every XCD has its own L2: with the
+// slices a multiple of 8 the tiles of one slice (which read the same dY / X pixels: a 128 x 128 gradient = 4 tiles reads every operand
+// twice) are given ids 8 apart, i.e. the same XCD at nearly the same time, so that the second reader hits that L2 instead of HBM.
+DEVI void wgrad_block(const WgradPlan& q, int& tile, int& slice) {
+    const int L = blockIdx.x;
+    if ((q.nslices & 7) == 0) { const int r = L >> 3; tile = r % q.tiles; slice = (L & 7) + 8 * (r / q.tiles); }
+    else { tile = L % q.tiles; slice = L / q.tiles; }
+}
 
 template <typename T> DEVI void wg_ld4(const T* p, float (&v)[4]);                       // 4 consecutive channels -> fp32
 template <> DEVI void wg_ld4<float>(const float* p, float (&v)[4]) { const float4 u = *reinterpret_cast<const float4*>(p); v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; }
@@ -108,7 +116,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const T* __restrict_
     int* pofs = reinterpret_cast<int*>(xS + WG_PATCH * WG_T);           // patch pixel of chunk pixel j (centre tap), -1: not a pixel
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hh = lane >> 5;
     const int tiles_ci = (Cin + WG_T - 1) / WG_T;
-    const int co0 = (blockIdx.x / tiles_ci) * WG_T, ci0 = (blockIdx.x % tiles_ci) * WG_T;
+    int tile_i, slice_i;
+    wgrad_block(q, tile_i, slice_i);
+    const int co0 = (tile_i / tiles_ci) * WG_T, ci0 = (tile_i % tiles_ci) * WG_T;
     const int wm = wave >> 1, wn = wave & 1;                            // this wave's 32 x 32 quadrant of the tile
     const int PWp = q.CW + 2, npatch = (q.RH + 2) * PWp, nchunk = q.RH * q.CW;
     if (t < WG_PX) pofs[t] = t < nchunk ? (t / q.CW + 1) * PWp + t % q.CW + 1 : -1;
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const T* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
     float bsum = 0.f;
-    const int u_lo = blockIdx.y * q.per_slice, u_hi = min(u_lo + q.per_slice, q.units);
+    const int u_lo = slice_i * q.per_slice, u_hi = min(u_lo + q.per_slice, q.units);
     const int rows_per_img = H / q.RH;
     // Register double buffering (as wgrad16_kernel): the float4 pieces of chunk u + 1 (4 of dY, up to 7 of the patch per thread) are
     // requested before the 288 MFMAs of chunk u and stored to LDS after them.  The synchronous form ran at 0.56 of the fp32 MFMA rate
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const T* __restrict_
             }
         }
     }
-    float* o = part + (size_t)blockIdx.y * Cout * Cin * NT;
+    float* o = part + (size_t)slice_i * Cout * Cin * NT;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, ci = ci0 + wn * 32 + l31;
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const T* __restrict_
     }
     if (bpart && ci0 == 0 && wn == 0) {                                // bias gradient: column sums of dY, once per co tile and slice
         bsum += __shfl_xor(bsum, 32);
-        if (hh == 0 && co0 + wm * 32 + l31 < Cout) bpart[(size_t)blockIdx.y * Cout + co0 + wm * 32 + l31] = bsum;
+        if (hh == 0 && co0 + wm * 32 + l31 < Cout) bpart[(size_t)slice_i * Cout + co0 + wm * 32 + l31] = bsum;
     }
 }
 // ---- weight gradient of 16-bit tensors on the 16-bit matrix pipe (mixed-precision training) -------------------------------------------
@@ -244,7 +254,9 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const T* __restrict__ d
                                                                         // (always staged: dY is zero there, but 0 x stale LDS bits could be NaN)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hh = lane >> 5;
     const int tiles_ci = (Cin + WG_T - 1) / WG_T;
-    const int co0 = (blockIdx.x / tiles_ci) * WG_T, ci0 = (blockIdx.x % tiles_ci) * WG_T;
+    int tile_i, slice_i;
+    wgrad_block(q, tile_i, slice_i);
+    const int co0 = (tile_i / tiles_ci) * WG_T, ci0 = (tile_i % tiles_ci) * WG_T;
     const int wm = wave >> 1, wn = wave & 1;
     const int PWp = q.CW + 2, npatch = (q.RH + 2) * PWp, nchunk = q.RH * q.CW;
     if (t < WG_PX) pofs[t] = t < nchunk ? (t / q.CW + 1) * PWp + t % q.CW + 1 : PWp + 1;
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const T* __restrict__ d
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
     float bsum = 0.f;
     const bool want_b = bpart && ci0 == 0 && wn == 0;
-    const int u_lo = blockIdx.y * q.per_slice, u_hi = min(u_lo + q.per_slice, q.units);
+    const int u_lo = slice_i * q.per_slice, u_hi = min(u_lo + q.per_slice, q.units);
     const int rows_per_img = H / q.RH;
     // Register double buffering: the 16-byte pieces of chunk u + 1 (2 of dY, up to 5 of the patch per thread) are requested before the
     // MFMAs of chunk u and stored to LDS after them, so their latency hides behind the 36 MFMAs (PMC of the synchronous form: waves
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const T* __restrict__ d
             }
         }
     }
-    float* o = part + (size_t)blockIdx.y * Cout * Cin * NT;
+    float* o = part + (size_t)slice_i * Cout * Cin * NT;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, ci = ci0 + wn * 32 + l31;
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const T* __restrict__ d
     }
     if (want_b) {                                                      // bias gradient: column sums of dY, once per co tile and slice
         bsum += __shfl_xor(bsum, 32);
-        if (hh == 0 && co0 + wm * 32 + l31 < Cout) bpart[(size_t)blockIdx.y * Cout + co0 + wm * 32 + l31] = bsum;
+        if (hh == 0 && co0 + wm * 32 + l31 < Cout) bpart[(size_t)slice_i * Cout + co0 + wm * 32 + l31] = bsum;
     }
 }
 
@@ -793,6 +805,7 @@ static WgradPlan wgrad_plan(int B, int H, int W, int Cout, int Cin, int cw_max =
     ns = std::min(ns, std::max(1, q.units / 4));                      // ... of at least 4 chunks each
     q.per_slice = (q.units + ns - 1) / ns;
     q.nslices = (q.units + q.per_slice - 1) / q.per_slice;
+    q.tiles = tiles;
     return q;
 }
 static int g_wgrad_mfma16 = 1;        // 16-bit tensors: 1 = wgrad16_kernel (16-bit MFMA), 0 = wgrad_tile_kernel (converted while staging, fp32 MFMA)
@@ -812,7 +825,7 @@ static void wgrad_tile_t(const void* dy, const void* x, float* part, float* bpar
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel<1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
         attr = true;
     }
-    const dim3 grid(((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T), q.nslices);
+    const dim3 grid(q.tiles * q.nslices);
     if (ntaps == 9) hipLaunchKernelGGL((wgrad_tile_kernel<9, T>), grid, dim3(256), WG_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
     else            hipLaunchKernelGGL((wgrad_tile_kernel<1, T>), grid, dim3(256), WG_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
 }
@@ -825,7 +838,7 @@ static void wgrad16_t(const void* dy, const void* x, float* part, float* bpart, 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel<1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WH_SMEM);
         attr = true;
     }
-    const dim3 grid(((Cout + WG_T - 1) / WG_T) * ((Cin + WG_T - 1) / WG_T), q.nslices);
+    const dim3 grid(q.tiles * q.nslices);
     if (ntaps == 9) hipLaunchKernelGGL((wgrad16_kernel<9, T>), grid, dim3(256), WH_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
     else            hipLaunchKernelGGL((wgrad16_kernel<1, T>), grid, dim3(256), WH_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
 }
