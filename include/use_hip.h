@@ -229,7 +229,8 @@ int use_op_gn_finalize(const long long* st0, int C0, const long long* st1, int C
  *                    given), dgamma, dbeta; `work`: use_op_gn_workspace(B, C, groups) floats of scratch, 8-byte aligned; have_stats != 0:
  *                    `work` is the workspace use_op_gn_act_fwd ran in for the same x, whose statistics are reused.
  * use_op_gn_act_fwd: y = act(GroupNorm(x)) (the operand of the following convolution's weight gradient, recomputed); same workspace.
- * use_op_colsum:     out[b][c] = scale * sum_p x[b,p,c]            (the gradient reaching Dense_0's output)
+ * use_op_colsum:     out[b][c] = scale * sum_p x[b,p,c] (fp32 out; the gradient reaching Dense_0's output); work: 128 B C floats of
+ *                    scratch (8-byte aligned) for the pixel-sliced kernel, or null (fp32 input only: one workgroup per 64 channels).
  * use_op_dense_bwd:  Dense_0(SiLU(temb)): g [B][Cout] -> dW [Cout][K], db [Cout], dtemb [B][K].
  * use_op_attention_bwd: the AttnBlockpp core, out = softmax(q k^T / sqrt(C)) v: dq, dk, dv from dO ([B][N][C] each; work: 2 B N N floats). */
 size_t use_op_wgrad_workspace(int B, int H, int W, int Cout, int Cin, int ntaps, int dtype);
@@ -240,7 +241,7 @@ int use_op_gn_act_bwd(const void* x, const void* dy, int dtype, const float* gam
                       float add_scale, int B, int HW, int C, float* work, int have_stats, void* dx, float* dgamma, float* dbeta, use_stream_t stream);
 int use_op_gn_act_fwd(const void* x, int dtype, const float* gamma, const float* beta, int groups, float eps, int act, int B, int HW, int C, float* work,
                       void* y, use_stream_t stream);
-int use_op_colsum(const float* x, int B, int HW, int C, float scale, float* out, use_stream_t stream);
+int use_op_colsum(const void* x, int dtype, int B, int HW, int C, float scale, float* out, float* work, use_stream_t stream);
 int use_op_dense_bwd(const float* g, const float* temb, const float* Wd, int B, int K, int Cout, float* dW, float* db, float* dtemb,
                      use_stream_t stream);
 int use_op_attention_bwd(const float* q, const float* k, const float* v, const float* dO, float* work, float* dq, float* dk, float* dv, int B, int N,

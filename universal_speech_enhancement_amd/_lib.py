@@ -98,7 +98,7 @@ SYMBOLS = {
     "use_op_gn_workspace": (C.c_size_t, [_i, _i, _i]),
     "use_op_gn_act_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _f, _i, _vp, _f, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "use_op_gn_act_fwd": (_i, [_vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "use_op_colsum": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
+    "use_op_colsum": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "use_op_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "use_op_dense_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "use_wav_read": (_i, [C.c_char_p, C.POINTER(C.POINTER(C.c_double)), C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),

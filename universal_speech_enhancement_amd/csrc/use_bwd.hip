@@ -528,6 +528,44 @@ __global__ __launch_bounds__(256) void gn_stats_part_kernel(const T* __restrict_
         o[0] = a; o[1] = e;
     }
 }
+// per-(item, channel) sums over the pixels, sliced like gn_stats_part_kernel: part[b][slice][c] (fp64)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ x, int HW, int C, double* __restrict__ part) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float sh[256 * VEC];
+    const int tpp = C / VEC, ppi = 256 / tpp, t = threadIdx.x, b = blockIdx.y, ns = gridDim.x;
+    const int per = (HW + ns - 1) / ns, lo = blockIdx.x * per, hi = lo + per < HW ? lo + per : HW;
+    const bool on = t < tpp * ppi;
+    const int pl = t / tpp, c4 = (t % tpp) * VEC;
+    float s[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s[k] = 0.f;
+    if (on) {
+        for (int p = lo + pl; p < hi; p += ppi) {
+            float v[VEC];
+            Vec16<T>::load(x + ((size_t)b * HW + p) * C + c4, v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s[k] += v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) sh[pl * C + c4 + k] = s[k];
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        double a = 0.0;
+        for (int l = 0; l < ppi; ++l) a += sh[l * C + c];
+        part[((size_t)b * ns + blockIdx.x) * C + c] = a;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_fin_kernel(const double* __restrict__ part, int ns, int C, int BC, float scale, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= BC) return;
+    const int b = i / C, c = i % C;
+    double a = 0.0;
+    for (int sl = 0; sl < ns; ++sl) a += part[((size_t)b * ns + sl) * C + c];
+    out[i] = (float)(a * scale);
+}
+
 // one wave per (item, group): the slices are summed across the lanes
 __global__ __launch_bounds__(64) void gn_stats_fin_kernel(const double* __restrict__ part, int ns, int G, double n, float eps,
                                                           float* __restrict__ mean, float* __restrict__ rstd) {
@@ -961,8 +999,23 @@ bool launch_gn_act_fwd(const void* x, int dtype, const float* mean, const float*
     else     hipLaunchKernelGGL(gn_act_fwd_kernel<false>, dim3(blocks), dim3(256), 0, s, (const float*)x, mean, rstd, gamma, beta, HW, C, G, (float*)y, n);
     return true;
 }
-void launch_colsum(const float* x, int B, int HW, int C, float scale, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, x, HW, C, scale, out);
+template <typename T>
+static void colsum_t(const void* x, int B, int HW, int C, float scale, float* out, double* part, hipStream_t s) {
+    const int ns = std::min(64, gn_slices(HW, C, Vec16<T>::N));          // <= 64 slices: the finishing kernel walks them serially
+    hipLaunchKernelGGL(colsum_part_kernel<T>, dim3(ns, B), dim3(256), 0, s, (const T*)x, HW, C, part);
+    hipLaunchKernelGGL(colsum_fin_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, part, ns, C, B * C, scale, out);
+}
+// x in `dtype`; part = nullptr: the one-block-per-(item, 64 channels) fp32 kernel.  work: 2 * 64 * B * C floats (fp64 partials)
+bool launch_colsum(const void* x, int dtype, int B, int HW, int C, float scale, float* out, double* part, hipStream_t s) {
+    if (part && gn_sliced(C, 1, dtype)) {
+        if (dtype == DT_F32) colsum_t<float>(x, B, HW, C, scale, out, part, s);
+        else if (dtype == DT_BF16) colsum_t<__bf16>(x, B, HW, C, scale, out, part, s);
+        else colsum_t<_Float16>(x, B, HW, C, scale, out, part, s);
+        return true;
+    }
+    if (dtype != DT_F32) return false;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, (const float*)x, HW, C, scale, out);
+    return true;
 }
 void launch_dense_bwd(const float* g, const float* temb, const float* Wd, int B, int K, int Cout, float* dW, float* db, float* dtemb, hipStream_t s) {
     hipLaunchKernelGGL(dense_bwd_kernel, dim3(1), dim3(256), 0, s, g, temb, Wd, B, K, Cout, dW, db, dtemb);

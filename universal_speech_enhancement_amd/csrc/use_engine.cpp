@@ -1843,9 +1843,12 @@ int use_op_gn_act_fwd(const void* x, int dtype, const float* gamma, const float*
     HIPCHK(hipGetLastError());
     return USE_OK;
 }
-int use_op_colsum(const float* x, int B, int HW, int C, float scale, float* out, use_stream_t stream) {
-    if (!x || !out) return fail(USE_E_INVALID, "use_op_colsum: null tensor");
-    launch_colsum(x, B, HW, C, scale, out, (hipStream_t)stream);
+int use_op_colsum(const void* x, int dtype, int B, int HW, int C, float scale, float* out, float* work, use_stream_t stream) {
+    if (!x || !out || B < 1 || HW < 1 || C < 1) return fail(USE_E_INVALID, "use_op_colsum: bad argument");
+    if (dtype != DT_F32 && dtype != DT_BF16 && dtype != DT_F16) return fail(USE_E_INVALID, "use_op_colsum: bad dtype");
+    if (work && (uintptr_t)work % 8) return fail(USE_E_INVALID, "use_op_colsum: workspace must be 8-byte aligned");
+    if (!launch_colsum(x, dtype, B, HW, C, scale, out, (double*)work, (hipStream_t)stream))
+        return fail(USE_E_INVALID, "use_op_colsum: 16-bit tensors need the workspace (128 B C floats) and C a multiple of 8");
     HIPCHK(hipGetLastError());
     return USE_OK;
 }

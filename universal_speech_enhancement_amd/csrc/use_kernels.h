@@ -186,7 +186,7 @@ bool launch_gn_act_bwd(const void* x, const void* dy, int dtype, const float* me
                        float* dgamma, float* dbeta, hipStream_t s);
 bool launch_gn_act_fwd(const void* x, int dtype, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int B, int HW,
                        int C, int G, void* y, hipStream_t s);
-void launch_colsum(const float* x, int B, int HW, int C, float scale, float* out, hipStream_t s);       // out[b][c] = scale * sum_p x[b,p,c]
+bool launch_colsum(const void* x, int dtype, int B, int HW, int C, float scale, float* out, double* part, hipStream_t s);       // out[b][c] = scale * sum_p x[b,p,c]
 // attention core backward (q, k, v, dO, dq, dk, dv: [B][N][C] fp32; work: 2 B N N floats)
 void launch_attention_bwd(const float* q, const float* k, const float* v, const float* dO, float* work, float* dq, float* dk, float* dv, int B,
                           int N, int C, hipStream_t s);

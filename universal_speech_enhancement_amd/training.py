@@ -78,7 +78,7 @@ class _Conv(torch.autograd.Function):
         if ctx.res_dtype is not None and ctx.needs_input_grad[5]:
             g_res = (gy * ctx.scale).to(ctx.res_dtype)
         if ctx.has_temb and ctx.needs_input_grad[4]:
-            g_temb = gy.sum((1, 2), dtype=torch.float32) * ctx.scale
+            g_temb = ops.colsum(gy.contiguous(), scale=ctx.scale)
         # the 2/4/6-channel ends of a 16-bit network change type: the backward runs in the 16-bit one (fp32 input, 16-bit output: the
         # weight gradient takes the input rounded to 16 bits - its products then run at the 16-bit MFMA rate; the input needs no gradient)
         if gy.dtype != x.dtype:

@@ -132,9 +132,11 @@ def dense_bwd(g, temb, Wd):
 
 
 def colsum(x, scale=1.0):
+    """out[b][c] = scale * sum over the pixels of x[b, :, :, c] (fp32; ``use_op_colsum``, pixel-sliced kernel)."""
     B, H, W, Cc = x.shape
-    out = torch.empty(B, Cc, device=x.device)
-    check(_lib.lib().use_op_colsum(_p(x), B, H * W, Cc, scale, _p(out), _stream()), "use_op_colsum")
+    out = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    work = torch.empty(128 * B * Cc, dtype=torch.float32, device=x.device)
+    check(_lib.lib().use_op_colsum(_p(x), dtype_code(x), B, H * W, Cc, scale, _p(out), _p(work), _stream()), "use_op_colsum")
     return out
 
 
