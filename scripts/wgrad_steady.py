@@ -2,7 +2,6 @@
 operands that fit the 256 MB last-level cache - against the rate the kernel shows inside a training step."""
 import os
 import sys
-import time
 
 import torch
 
