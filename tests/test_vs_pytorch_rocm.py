@@ -52,7 +52,7 @@ def test_score_evaluation_and_training_step_against_pytorch_rocm_eager(monkeypat
     assert float((got - ref).abs().max()) < 4e-2 * float(ref.abs().max())
     print(f"\n[measured] one score evaluation, B={B} x {T} frames: PyTorch-ROCm eager fp32 {t_torch * 1e3:.1f} ms, fp16 autocast {t_torch16 * 1e3:.1f} ms; "
           f"HIP path fp32 {t_hip32 * 1e3:.1f} ms, bf16 {t_hip * 1e3:.1f} ms ({t_torch / t_hip:.1f}x the fp32 eager run)")
-    assert t_hip < t_torch16 < t_torch * 1.2 and t_hip32 < t_torch
+    assert t_hip < min(t_torch, t_torch16) and t_hip32 < t_torch
     del got, got32, ref
     # ---- one training step (forward + backward of a squared-error loss on the network output; no optimiser) -------------------------
     Bt, Tt = (4, 512) if FULL else (2, 64)
