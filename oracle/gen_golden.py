@@ -21,6 +21,8 @@ Fixtures
   sample_cfg1.npz   BASELINE cfg1: 2 s utterance, N=5, reverse_diffusion+langevin    (G5, ~70 s)
   sample_denoised.npz ScoreModel.sample with condition="denoised", sde_input in {noisy, denoised}  (model_wrapper.py:283-328)
   forward_12m/6m.npz NCSNpp12M / NCSNpp6M (nf = 96) forward [2,2,512,64]                  
+  lowprec_reference.npz  the reference's OWN 16-bit errors (CPU autocast forward bf16 / fp16, bf16-autocast backward) vs its fp32
+                    results: the bounds the HIP 16-bit paths are held to
   refine.npz        LSGAN refine generator: NCSNpp(discriminative=True).forward [2,1,512,64] and
                     NCSNPP_Wrapper inference on 2 x 0.4 s                           
 """
@@ -417,6 +419,129 @@ def gen_refine(model=None):
              weights_seed=4321, weights_crc=crc)
 
 
+def gen_lowprec(model=None):
+    """What the REFERENCE itself does in 16-bit arithmetic - the yardstick for the 16-bit tolerances of the HIP path (tests assert
+    "no worse than the reference's own reduced-precision run", never "2x what we measured last time").
+      forward: NCSNppLarge.forward on the forward_large inputs under torch.autocast("cpu", bfloat16 / float16) against its own fp32
+               output: error relative to the maximum and relative L2, per t-pair.
+      training: the reference's loss.backward() of gen_train_grads case a under bf16 autocast against its fp32 gradients: loss,
+               worst gradient-norm error, and per-tensor relative L2 errors (all 616 tensors: max, 99th / 95th percentile, median)."""
+    m, crc = model or build_reference_large()
+    g = dict(np.load(os.path.join(OUT, "forward_large.npz")))
+    x = torch.from_numpy(g["x"])
+    out = {}
+    for dt_name, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        for tag in ("a", "b"):
+            t = torch.from_numpy(g["t_" + tag])
+            ref = torch.from_numpy(g["out_" + tag])
+            try:
+                with torch.no_grad(), torch.autocast("cpu", dtype=dt):
+                    low = m.score_net(x, t)
+            except Exception as e:   # noqa: BLE001
+                print("  autocast", dt_name, "unsupported on this CPU build:", e)
+                continue
+            d = (torch.view_as_real(low.to(torch.complex64)) - torch.view_as_real(ref)).double()
+            out[f"fwd_{dt_name}_relmax_{tag}"] = np.float64(d.abs().max() / ref.abs().max())
+            out[f"fwd_{dt_name}_rell2_{tag}"] = np.float64(d.norm() / torch.view_as_real(ref).double().norm())
+            print(f"  forward {dt_name} {tag}: relmax {out[f'fwd_{dt_name}_relmax_{tag}']:.4g} rel-L2 {out[f'fwd_{dt_name}_rell2_{tag}']:.4g}", flush=True)
+    # the benchmarked sampler as a chain: 30 PC steps (reverse_diffusion + Langevin x1 = 60 evaluations, t down to 0.03, the score's
+    # 1/t amplification included) on one 0.4 s utterance, the reference under bf16 / fp16 autocast vs its own fp32 run, same noise:
+    # how far the REFERENCE drifts in 16 bits (spectrogram fed to spec_back and waveform; relative to the maximum and relative L2)
+    wav = torch.from_numpy(tnoise.synth_noisy_speech(1, 9600, seed=77))
+    N_chain = 30
+    draws = tnoise.sampler_noise(4321, 1 + 2 * N_chain, (1, 1, 512, 64))
+    chain = {}
+    for dt_name, dt in (("fp32", None), ("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        grabbed = {}
+        orig_back = m.spec_back
+        m.spec_back = lambda spec, _o=orig_back, _g=grabbed: (_g.__setitem__("spec", spec.clone()), _o(spec))[1]
+        orig = torch.randn_like
+        torch.randn_like = _Replay(list(draws))
+        try:
+            with torch.no_grad():
+                if dt is None:
+                    w = m.sample({"perturbed": wav.clone()}, N=N_chain, corrector_steps=1, snr=0.5)["enhanced"]
+                else:
+                    with torch.autocast("cpu", dtype=dt):
+                        w = m.sample({"perturbed": wav.clone()}, N=N_chain, corrector_steps=1, snr=0.5)["enhanced"]
+        finally:
+            torch.randn_like = orig
+            m.spec_back = orig_back
+        chain[dt_name] = (torch.view_as_real(grabbed["spec"].to(torch.complex64)).double(), w.double())
+        print("  chain", dt_name, "done", flush=True)
+    for dt_name in ("bf16", "fp16"):
+        for what, i in (("spec", 0), ("wav", 1)):
+            ref, low = chain["fp32"][i], chain[dt_name][i]
+            out[f"chain_{dt_name}_{what}_relmax"] = np.float64((low - ref).abs().max() / ref.abs().max())
+            out[f"chain_{dt_name}_{what}_rell2"] = np.float64((low - ref).norm() / ref.norm())
+        print("  chain", dt_name, {k: float(v) for k, v in out.items() if k.startswith(f"chain_{dt_name}")}, flush=True)
+    out["chain_N"] = N_chain
+    # the refine generator (NCSNpp(discriminative=True), LSGAN stage) under bf16 autocast: the refine.npz input and the T' = 128 input of
+    # tests/test_hip_parity.py::test_refine_generator_long_sequence_attention (1024-token attention)
+    sdr = tw.make_state_dict(4321, **tw.REFINE)
+    try:
+        gr = dict(np.load(os.path.join(OUT, "refine.npz")))
+        import src.models.components.GAN.generator.ncsnpp.model_wrapper as GW
+        wr = GW.NCSNPP_Wrapper(n_fft=1022, hop_length=160, num_frames=480, window="hann", spec_factor=0.15, spec_abs_exponent=0.5).eval()
+        wr.net.load_state_dict({k: torch.from_numpy(v) for k, v in sdr.items()}, strict=True)
+        for tag, xin in (("golden", torch.from_numpy(gr["x"])), ("t128", torch.from_numpy(tnoise.complex_normal(31, "Y", (1, 1, 512, 128))) * 0.5)):
+            with torch.no_grad():
+                r32 = wr.net(xin)
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    r16 = wr.net(xin)
+            d = (torch.view_as_real(r16.to(torch.complex64)) - torch.view_as_real(r32)).double()
+            out[f"refine_bf16_relmax_{tag}"] = np.float64(d.abs().max() / r32.abs().max())
+            print(f"  refine bf16 {tag}: relmax {out[f'refine_bf16_relmax_{tag}']:.4g}", flush=True)
+    except Exception as e:   # noqa: BLE001
+        print("  refine figures skipped:", repr(e))
+    # training gradients under bf16 autocast (case a of gen_train_grads)
+    import src.models.components.sgmse.model_wrapper as MW
+    L, arch = 12000, tw.LARGE
+    clean = torch.from_numpy(tnoise.synth_noisy_speech(2, L, seed=91))
+    noisy = 0.8 * clean + 0.2 * torch.from_numpy(tnoise.synth_noisy_speech(2, L, seed=92))
+    fake = 0.9 * clean + 0.1 * torch.from_numpy(tnoise.synth_noisy_speech(2, L, seed=93))
+    t = torch.tensor([0.31, 0.87], dtype=torch.float32)
+    z = torch.from_numpy(tnoise.complex_normal(55, "train_z_a", (2, 1, 512, 64)))
+    start = 1234
+    sd = tw.make_state_dict(1234, **arch)
+    grads = {}
+    for mode in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        mm = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition="noisy", loss_type="mse", n_fft=1022,
+                        hop_length=160, num_frames=64, window="hann", sde_input="noisy").eval()
+        mm.score_net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        o_rand, o_randn, o_unif = torch.rand, torch.randn_like, MW.np.random.uniform
+        torch.rand = lambda *a, **k: (t - mm.t_eps) / (mm.sde.T - mm.t_eps)
+        torch.randn_like = lambda like, **k: z.clone()
+        MW.np.random.uniform = lambda lo, hi: start
+        try:
+            if mode == "bf16":
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    loss = mm.train_step({"clean": clean.clone(), "perturbed": noisy.clone(), "fake": fake.clone()})
+            else:
+                loss = mm.train_step({"clean": clean.clone(), "perturbed": noisy.clone(), "fake": fake.clone()})
+        finally:
+            torch.rand, torch.randn_like, MW.np.random.uniform = o_rand, o_randn, o_unif
+        loss.backward()
+        grads[mode] = (float(loss.item()), {k: p.grad.detach().double() for k, p in mm.score_net.named_parameters() if p.grad is not None})
+    (l32, g32), (l16, g16) = grads["fp32"], grads["bf16"]
+    rel = []
+    worst_n = 0.0
+    for k, a in g32.items():
+        na = float(a.norm())
+        if na < 1e-12 or k.endswith("NIN_1.b"):      # the key bias of an attention block: its gradient is analytically zero (softmax is
+            continue                                  # shift-invariant), what is stored is rounding noise
+        rel.append(float((g16[k] - a).norm()) / na)
+        worst_n = max(worst_n, abs(float(g16[k].norm()) - na) / na)
+    rel = np.sort(np.array(rel))
+    out.update(train_bf16_loss_rel=np.float64(abs(l16 - l32) / abs(l32)), train_bf16_norm_rel_max=np.float64(worst_n),
+               train_bf16_tensor_rell2_max=np.float64(rel[-1]), train_bf16_tensor_rell2_p99=np.float64(rel[int(0.99 * (len(rel) - 1))]),
+               train_bf16_tensor_rell2_p95=np.float64(rel[int(0.95 * (len(rel) - 1))]), train_bf16_tensor_rell2_median=np.float64(np.median(rel)),
+               train_n_tensors=len(rel))
+    print("  training bf16 autocast:", {k: float(v) for k, v in out.items() if k.startswith("train_")}, flush=True)
+    np.savez(os.path.join(OUT, "lowprec_reference.npz"), weights_seed=1234, weights_crc=crc, **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -426,7 +551,7 @@ if __name__ == "__main__":
              "refine": gen_refine, "forward_small": gen_forward_small, "both": gen_both,
              "train_loss": gen_train_loss, "train_grads": gen_train_grads}
     big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1,
-           "sample_denoised": gen_sample_denoised}
+           "sample_denoised": gen_sample_denoised, "lowprec": gen_lowprec}
     todo = [a.only] if a.only else list(small) + list(big)
     model = build_reference_large() if any(n in big for n in todo) else None
     for n in todo:

@@ -1,0 +1,60 @@
+"""Where the 16-bit tolerances of the GPU tests come from: the REFERENCE's own reduced-precision error, not this build's last run.
+
+``tests/golden/lowprec_reference.npz`` (``oracle/gen_golden.py --only lowprec``, run against /root/reference) holds what the reference's
+own modules do under ``torch.autocast("cpu", bfloat16 / float16)`` relative to their fp32 results:
+
+  fwd_*     one NCSNppLarge evaluation on the forward_large inputs (two t pairs)                      bf16 2.33e-2 / fp16 3.33e-3 of max
+  refine_*  one evaluation of the LSGAN refine generator (golden input, T' = 128 input)               bf16 2.39e-2
+  chain_*   the benchmarked sampler as a chain: 30 PC steps = 60 evaluations, one 0.4 s utterance     bf16 spec 2.46e-2 / wav 2.17e-2 (max),
+                                                                                                      1.14e-2 / 1.99e-2 (L2); fp16 ~ 1/10
+  train_*   loss.backward() of train_step under bf16 autocast (615 gradient tensors)                  loss 2.6e-3, norms 1.6e-2, tensors 3.5e-2 (L2)
+
+Rules (each bound is a stated multiple of the reference-side figure):
+  * one network evaluation: the HIP 16-bit mode may not be worse than the reference's own 16-bit run: factor 1.0 (the maximum over
+    the stored t pairs).  Long-sequence attention (1024 tokens, probabilities rounded to 16 bits for the P.V GEMM): factor 1.25.
+  * chained sampler outputs (N evaluations, spectrogram or waveform): factor 2.5 of the reference's 60-evaluation chain figure.  The HIP
+    modes store EVERY activation tensor in 16 bits (that is what halves the HBM traffic), autocast rounds only the convolution /
+    matmul operands and keeps GroupNorm, SiLU and the residual sums in fp32; and the maximum is taken over up to 80x more elements
+    (B = 8, T' = 640 against the fixture's 1 x 64 frames).
+  * fp16 figures that the CPU cannot produce (training backward) are the bf16 figures / 4 (three more mantissa bits = 8x, halved for
+    the same storage argument).
+  * single operators: k units in the last place of the storage type relative to the tensor maximum (bf16: 2^-8, fp16: 2^-11), k = 4:
+    two roundings of the input / weights, one of the output, and the K-long fp32 accumulation order.
+"""
+import os
+
+import numpy as np
+
+_G = None
+
+
+def ref16(key: str) -> float:
+    global _G
+    if _G is None:
+        _G = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lowprec_reference.npz")))
+    return float(_G[key])
+
+
+def fwd_bound(prec: str, factor: float = 1.0) -> float:
+    """One score-network evaluation, error relative to the reference tensor's maximum."""
+    return factor * max(ref16(f"fwd_{prec}_relmax_a"), ref16(f"fwd_{prec}_relmax_b"))
+
+
+def refine_bound(prec: str = "bf16", factor: float = 1.0) -> float:
+    return factor * max(ref16(f"refine_{prec}_relmax_golden"), ref16(f"refine_{prec}_relmax_t128"))
+
+
+def chain_bound(prec: str, what: str, norm: str, factor: float = 2.5) -> float:
+    """what: 'spec' | 'wav'; norm: 'relmax' | 'rell2'."""
+    return factor * ref16(f"chain_{prec}_{what}_{norm}")
+
+
+def train_bound(prec: str, what: str, factor: float = 1.0) -> float:
+    """what: 'loss_rel' | 'norm_rel_max' | 'tensor_rell2_max'."""
+    v = ref16(f"train_bf16_{what}")
+    return factor * (v if prec == "bf16" else v / 4.0)
+
+
+def op_bound(dtype, k: float = 4.0) -> float:
+    """Single operators: k ulps of the storage type (dtype: 1 / 'bf16', 2 / 'fp16')."""
+    return k * (2.0 ** -8 if dtype in (1, "bf16") else 2.0 ** -11)

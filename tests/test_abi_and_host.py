@@ -216,12 +216,24 @@ def test_packed_weight_file_is_written_on_the_host(tmp_path):
 
 def test_train_step_refuses_frame_counts_it_would_have_to_pad():
     """The reference's train_step feeds the UNPADDED num_frames-frame spectrogram to the network (model_wrapper.py:168-171), which only
-    closes for multiples of 64 frames; the stand-in must not silently zero-pad another count (extra frames in z and in the loss)."""
+    closes for multiples of 2^(levels - 1) frames (64 for the 7-level NCSN++, 8 for the 4-level nf = 96 networks); the stand-in must not
+    silently zero-pad another count (extra frames in z and in the loss).  The divisor follows the backbone."""
     import torch
     from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel
-    m = ScoreModel(backbone="none", sde="ouve", condition="noisy", sde_input="noisy", n_fft=1022, hop_length=160, num_frames=100)
+    batch = {"clean": torch.zeros(1, 20000), "perturbed": torch.zeros(1, 20000)}
+    m = ScoreModel(backbone="ncsnpplarge", sde="ouve", condition="noisy", sde_input="noisy", n_fft=1022, hop_length=160, num_frames=100)
     with pytest.raises(ValueError, match="multiple of 64"):
-        m.train_step({"clean": torch.zeros(1, 20000), "perturbed": torch.zeros(1, 20000)})
+        m.train_step(dict(batch))
+    m = ScoreModel(backbone="ncsnpp6M", sde="ouve", condition="noisy", sde_input="noisy", n_fft=254, hop_length=64, num_frames=100)
+    with pytest.raises(ValueError, match="multiple of 8 "):
+        m.train_step(dict(batch))
+    m = ScoreModel(backbone="ncsnpp6M", sde="ouve", condition="noisy", sde_input="noisy", n_fft=254, hop_length=64, num_frames=104)
+    try:                                  # 104 = 13 x 8 frames passes the check (and then needs a GPU: any other error is fine here)
+        m.train_step(dict(batch))
+    except ValueError as e:
+        assert "multiple of" not in str(e)
+    except Exception:                     # noqa: BLE001
+        pass
 
 
 def test_training_entry_points_refuse_without_a_tape_or_a_gpu():

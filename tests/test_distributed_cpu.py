@@ -56,12 +56,14 @@ def _grad_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     D.init_from_env(backend="gloo")
     torch.manual_seed(7)                                             # same parameters on both ranks
-    params = [torch.nn.Parameter(torch.randn(n)) for n in (5, 300, 2, 1000, 64)]
+    params = [torch.nn.Parameter(torch.randn(n)) for n in (5, 300, 2, 1000, 64, 7)]
     params[2].requires_grad_(False)                                  # frozen: skipped
     for i, p in enumerate(params):
-        if p.requires_grad and not (rank == 1 and i == 4):           # rank 1 has no gradient for the last one: contributes zeros
+        if i == 5:                                                   # trainable on paper, but no rank has a gradient (detached in the
+            continue                                                 # taped forward): must stay None, not become zeros
+        if p.requires_grad and not (rank == 1 and i == 4):           # rank 1 has no gradient for this one: contributes zeros
             p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
-    n = D.allreduce_gradients(params, bucket_bytes=2048)             # 2 KB buckets: [5, 300] | [1000] | [64]
+    n = D.allreduce_gradients(params, bucket_bytes=2048)             # the has-gradient mask + 2 KB buckets: [5, 300] | [1000] | [64]
     q.put((rank, n, [None if p.grad is None else float(p.grad[0]) for p in params],
            all(p.grad is None or bool((p.grad == p.grad[0]).all()) for p in params)))
     dist.barrier()
@@ -70,7 +72,7 @@ def _grad_worker(rank, world, port, q):
 
 def test_two_rank_gradient_allreduce_in_buckets():
     """Data-parallel training exchange: gradients averaged over the ranks in contiguous buckets; frozen parameters skipped; a parameter
-    without a gradient on one rank counts as zero there."""
+    without a gradient on one rank counts as zero there; one without a gradient on every rank keeps grad = None."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -80,6 +82,6 @@ def test_two_rank_gradient_allreduce_in_buckets():
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     for r, n, firsts, uniform in res:
-        assert n == 3 and uniform
-        assert firsts == [1.5, 3.0, None, 6.0, 2.5]                   # mean of (1, 2) x (i + 1); the last: (5 + 0) / 2
+        assert n == 4 and uniform
+        assert firsts == [1.5, 3.0, None, 6.0, 2.5, None]             # mean of (1, 2) x (i + 1); index 4: (5 + 0) / 2; index 5: untouched
     assert D.allreduce_gradients([torch.nn.Parameter(torch.zeros(3))]) == 0     # no process group: nothing to do

@@ -1,0 +1,168 @@
+"""GPU parity of the code path bench.py times: the fused sampler (use_sample) with the Langevin corrector on batches that
+are evaluated as two sub-batches on two streams (B >= 4), against the CPU oracle.
+
+LangevinCorrector takes its step size from norms averaged over the WHOLE batch (reference
+sgmse/sampling/correctors.py:45-63; loop order sampling/__init__.py:64-68), so the two sub-batch streams must be joined
+before the norms are reduced.  Items carry distinct gains so that their norms differ by an order of magnitude: a step size
+formed from one sub-batch alone would be off by far more than the tolerance.
+
+Also here: near-silent and all-zero batch items through one score evaluation (real predict batches are zero-padded to the
+longest item, reference data.py:36-42): the GroupNorm statistics are fixed-point totals (csrc/use_device.h), which must not
+round a quiet item's sums of squares to zero.
+"""
+import numpy as np
+import pytest
+import torch
+
+import lowprec as lp
+from oracle import ncsnpp_oracle as no
+from oracle import sde_oracle as so
+from universal_speech_enhancement_amd.testing import noise as tnoise
+from universal_speech_enhancement_amd.testing import weights as tw
+from universal_speech_enhancement_amd.testing.cpu import usable_cores
+
+pytestmark = pytest.mark.gpu
+
+GAINS = (1.0, 5.0, 0.2, 2.5, 0.5, 1.5, 0.1, 3.0)
+N_STEPS = 2
+
+
+def _relmax(a, b):
+    a, b = torch.as_tensor(a).cpu(), torch.as_tensor(b).cpu()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+@pytest.fixture(scope="module")
+def sd_np():
+    return tw.make_state_dict(1234, **tw.LARGE)
+
+
+def _model(sd_np, precision, use_graph):
+    from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel
+    m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition="noisy", n_fft=1022, hop_length=160, num_frames=512,
+                   window="hann", sde_input="noisy", predictor="reverse_diffusion", corrector="langevin", precision=precision,
+                   use_graph=use_graph)
+    m.score_net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    return m
+
+
+_oracle_cache = {}
+
+
+def _inputs_and_oracle(sd_np, B):
+    """0.4 s utterances (T' = 64) with per-item gains, injected noise; the oracle's ScoreModel.sample on the CPU (cached per B)."""
+    if B not in _oracle_cache:
+        torch.set_num_threads(usable_cores())
+        wav = torch.from_numpy(tnoise.synth_noisy_speech(B, 9600, seed=321)) * torch.tensor(GAINS[:B]).view(B, 1)
+        draws = tnoise.sampler_noise(55, 1 + 2 * N_STEPS, (B, 1, 512, 64))
+        sd = no.to_torch(sd_np)
+        with torch.no_grad():
+            ref, spec, _, nfe = so.score_model_sample(lambda xx, t: no.ncsnpp_forward(sd, xx, t), wav, N=N_STEPS, predictor="reverse_diffusion",
+                                                      corrector="langevin", corrector_steps=1, snr=0.5,
+                                                      noise=so.NoiseSource(replay=[torch.from_numpy(d) for d in draws]))
+        assert nfe == 2 * N_STEPS
+        _oracle_cache[B] = (wav, draws, ref, spec)
+    return _oracle_cache[B]
+
+
+@pytest.mark.parametrize("B", [5, 8])
+def test_fused_langevin_on_split_batches_matches_the_oracle_fp32(sd_np, B):
+    """B = 5 is evaluated as 3 + 2 items, B = 8 as 4 + 4 (the benchmarked split); hipGraph replay and eager launches."""
+    wav, draws, ref, spec = _inputs_and_oracle(sd_np, B)
+    outs = {}
+    for use_graph in (True, False):
+        m = _model(sd_np, "fp32", use_graph)
+        outs[use_graph] = m.sample({"perturbed": wav.cuda()}, N=N_STEPS, corrector_steps=1, snr=0.5, noise=torch.from_numpy(draws).cuda())["enhanced"].cpu()
+    for b in range(B):           # per item: a quiet item must not hide behind a loud one
+        err = _relmax(outs[True][b], ref[b])
+        print(f"[measured] fused langevin fp32 B={B} item {b} (gain {GAINS[b]}): {err:.3g} (bound 2e-3)")
+        assert err < 2e-3, (B, b, err)
+    assert torch.equal(outs[True], outs[False]), "hipGraph replay must be bit-identical to eager launches"
+
+
+def test_fused_langevin_step_size_really_couples_the_sub_batches(sd_np):
+    """Negative control for the test above: the same 8 items run as two independent batches of 4 give a different result
+    (their Langevin step sizes come from different batch means), so agreement with the oracle at B = 8 does pin the join."""
+    wav, draws, ref, _ = _inputs_and_oracle(sd_np, 8)
+    m = _model(sd_np, "fp32", True)
+    d = torch.from_numpy(draws).cuda()
+    halves = [m.sample({"perturbed": wav[i:i + 4].cuda()}, N=N_STEPS, corrector_steps=1, snr=0.5, noise=d[:, i:i + 4].contiguous())["enhanced"].cpu()
+              for i in (0, 4)]
+    err = _relmax(torch.cat(halves), ref)
+    assert err > 2e-2, f"independent half-batches should NOT reproduce the batch-coupled reference (got {err:.3g})"
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_fused_langevin_on_split_batches_16bit(sd_np, prec):
+    """The benchmarked storage types on the same call, per item against the fp32 oracle.  Bound: 2.5 x the reference's OWN 16-bit drift
+    of the sampler's waveform (CPU autocast of the reference against its fp32 run, tests/lowprec.py / golden/lowprec_reference.npz)."""
+    tol = lp.chain_bound(prec, "wav", "relmax")
+    B = 8
+    wav, draws, ref, _ = _inputs_and_oracle(sd_np, B)
+    m = _model(sd_np, prec, True)
+    out = m.sample({"perturbed": wav.cuda()}, N=N_STEPS, corrector_steps=1, snr=0.5, noise=torch.from_numpy(draws).cuda())["enhanced"].cpu()
+    for b in range(B):
+        err = _relmax(out[b], ref[b])
+        print(f"[measured] fused langevin {prec} B={B} item {b} (gain {GAINS[b]}): {err:.3g} (bound {tol:g})")
+        assert err < tol, (prec, b, err)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", lp.fwd_bound("bf16")), ("fp16", lp.fwd_bound("fp16"))])   # 16-bit: the reference's own autocast error
+def test_quiet_and_silent_items_through_one_score_evaluation(sd_np, prec, tol):
+    """Item 0 ordinary, item 1 the same signal x 1e-3, item 2 all zeros (x and Y): per-item error against the CPU oracle.
+    (the fixed-point sums of squares used to round a quiet item's partial sums to zero.)"""
+    from universal_speech_enhancement_amd.hip_engine import HipScoreEngine
+    torch.set_num_threads(usable_cores())
+    sh = (1, 1, 512, 64)
+    y0 = torch.from_numpy(tnoise.complex_normal(5, "Y", sh)) * 0.3
+    x0 = y0 + torch.from_numpy(tnoise.complex_normal(5, "x", sh)) * 0.2
+    Y = torch.cat([y0, y0 * 1e-3, torch.zeros_like(y0)])
+    x = torch.cat([x0, x0 * 1e-3, torch.zeros_like(x0)])
+    t = torch.full((3,), 0.4)
+    sd = no.to_torch(sd_np)
+    with torch.no_grad():
+        ref = -no.ncsnpp_forward(sd, torch.cat([x, Y], dim=1), t)
+    eng = HipScoreEngine(precision=prec)
+    eng.load_state_dict(sd_np)
+    try:
+        out = eng.score(x.cuda(), Y.cuda(), t.cuda()).cpu()
+    finally:
+        eng.close()
+    assert torch.isfinite(torch.view_as_real(out)).all()
+    for b, tag in enumerate(("ordinary", "x1e-3", "all-zero")):
+        err = _relmax(out[b], ref[b])
+        print(f"[measured] quiet items {prec} item {b} ({tag}): {err:.3g} (bound {tol:g})")
+        assert err < tol, (prec, tag, err)
+
+
+def test_parked_plans_do_not_survive_a_weight_blob_load(tmp_path, sd_np):
+    """plan A, plan B (A is parked with its time-embedding tables and graphs), load a DIFFERENT packed weight file,
+    plan A again: the sampler must run with the new weights' tables, i.e. equal a fresh handle that only ever saw the new file."""
+    from universal_speech_enhancement_amd.hip_engine import HipScoreEngine
+    sd2 = tw.make_state_dict(4242, **tw.LARGE)
+    y = torch.from_numpy(tnoise.complex_normal(9, "ypc", (2, 1, 512, 64))).cuda() * 0.5
+
+    def run(eng, Tp=64):
+        eng.plan(2, Tp)
+        eng.set_sampler(2, "reverse_diffusion", "langevin", 1, 0.5, 3e-2, use_graph=True)
+        out = eng.sample(y if Tp == 64 else torch.cat([y, y], dim=3).contiguous(), seed=5)
+        torch.cuda.synchronize()
+        return out.clone()
+
+    fresh = HipScoreEngine(precision="bf16")
+    fresh.load_state_dict(sd2)
+    path = str(tmp_path / "w2.usew")
+    fresh.save_weight_blob(path)
+    want = run(fresh)
+    fresh.close()
+    eng = HipScoreEngine(precision="bf16")
+    eng.load_state_dict(sd_np)
+    try:
+        old = run(eng)                 # plan A with the old weights
+        run(eng, 128)                  # plan B: A is parked
+        eng.load_weight_blob(path)
+        got = run(eng)                 # plan A again
+    finally:
+        eng.close()
+    assert not torch.equal(old, want)
+    assert torch.equal(got, want), "a parked plan kept the old weights' time-embedding tables across use_load_weight_blob"

@@ -75,12 +75,16 @@ def test_training_step_gradients_match_the_reference_backward(golden_dir, tag):
     print(f"[measured] train grads {tag}: worst norm rel {worst_n:.3g}, worst tensor rel-to-max {worst_t:.3g}, {n_checked} tensors")
 
 
-@pytest.mark.parametrize("prec,tol_loss,tol_norm,tol_tensor", [("bf16", 5.2e-3, 2.6e-2, 0.22), ("fp16", 5e-5, 4.5e-3, 2.7e-2)])
-def test_mixed_precision_gradients_stay_close_to_the_fp32_reference(golden_dir, prec, tol_loss, tol_norm, tol_tensor):
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_mixed_precision_gradients_stay_close_to_the_fp32_reference(golden_dir, prec):
     """score_net.train_precision = "bf16" / "fp16": activations and their gradients in 16 bits, convolutions on the 16-bit MFMA kernels,
-    parameters / weight gradients / statistics fp32 - against the reference's fp32 backward (case a).  Bounds about 2x the measured
-    deviations (printed): bf16 loss 2.6e-3, gradient norms 1.3e-2, worst stored tensor 0.11 of its maximum (rms over all stored entries
-    7.5e-3); fp16 4e-6 / 2.3e-3 / 1.3e-2 (no loss scaling: the gradients of this loss sit well inside fp16's range)."""
+    parameters / weight gradients / statistics fp32 - against the reference's fp32 backward (case a).  Bounds: what the REFERENCE's own
+    bf16-autocast backward does against its fp32 backward on this very case (tests/lowprec.py, golden/lowprec_reference.npz: loss 2.6e-3,
+    gradient norms 1.6e-2, worst per-tensor relative L2 3.5e-2 over 615 tensors), factor 1.25 for loss and norms, 1.5 for the per-tensor
+    relative L2 (taken here over the stored tensors and corners only); fp16 = the bf16 figures / 4.  No loss scaling: the gradients of
+    this loss sit well inside fp16's range."""
+    import lowprec as lp
+    tol_loss, tol_norm, tol_tensor = lp.train_bound(prec, "loss_rel", 1.25), lp.train_bound(prec, "norm_rel_max", 1.25), lp.train_bound(prec, "tensor_rell2_max", 1.5)
     m, batch, t, z, start, g = _case(golden_dir, "a")
     m.score_net.requires_grad_(True)
     m.score_net.train_precision = prec
@@ -90,7 +94,7 @@ def test_mixed_precision_gradients_stay_close_to_the_fp32_reference(golden_dir, 
     loss.backward()
     torch.cuda.synchronize()
     P = dict(m.score_net.named_parameters())
-    worst_n, worst_t, tot_num, tot_den = 0.0, 0.0, 0.0, 0.0
+    worst_n, worst_t, worst_name, tot_num, tot_den = 0.0, 0.0, None, 0.0, 0.0
     for key in g.files:
         kind, _, name = key.partition(".")
         if kind not in ("n", "g", "c") or name.endswith("NIN_1.b"):
@@ -100,12 +104,16 @@ def test_mixed_precision_gradients_stay_close_to_the_fp32_reference(golden_dir, 
         if kind == "n":
             worst_n = max(worst_n, abs(float(got.double().norm()) - float(g[key])) / float(g[key]))
         else:
-            ref = torch.from_numpy(g[key])
-            have = got.detach().cpu() if kind == "g" else got.detach()[:4, :4].cpu()
-            worst_t = max(worst_t, float((have - ref).abs().max()) / float(ref.abs().max()))
-            tot_num += float((have - ref).double().square().sum()); tot_den += float(ref.double().square().sum())
-    print(f"[measured] mixed {prec}: loss rel {e_loss:.3g}, worst norm rel {worst_n:.3g}, worst tensor rel-to-max {worst_t:.3g}, "
-          f"stored entries rms rel {np.sqrt(tot_num / tot_den):.3g}")
+            ref = torch.from_numpy(g[key]).double()
+            have = (got.detach().cpu() if kind == "g" else got.detach()[:4, :4].cpu()).double()
+            num, den = float((have - ref).square().sum()), float(ref.square().sum())
+            if kind == "g" and den > 0:                                  # whole tensors: the per-tensor relative L2 error
+                e = (num / den) ** 0.5
+                if e > worst_t:
+                    worst_t, worst_name = e, name
+            tot_num += num; tot_den += den
+    print(f"[measured] mixed {prec}: loss rel {e_loss:.3g} (bound {tol_loss:.3g}), worst norm rel {worst_n:.3g} (bound {tol_norm:.3g}), "
+          f"worst per-tensor rel-L2 {worst_t:.3g} at {worst_name} (bound {tol_tensor:.3g}), all stored entries rel-L2 {np.sqrt(tot_num / tot_den):.3g}")
     assert e_loss < tol_loss and worst_n < tol_norm and worst_t < tol_tensor
 
 

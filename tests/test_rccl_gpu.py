@@ -84,9 +84,11 @@ lo, hi = D.shard_bounds(x.shape[0], rank, world)                     # each rank
 loss = net(x[lo:hi], torch.tensor([0.4, 0.9], device="cuda")[lo:hi]).abs().square().mean()
 loss.backward()
 before = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
-n = D.allreduce_gradients(net.parameters())                          # 6 M fp32 gradients: one RCCL all-reduce
+assert not dict(net.named_parameters())["all_modules.0.W"].requires_grad   # the Fourier projection stays frozen (layerspp.py:35)
+n = D.allreduce_gradients(net.parameters())                          # the has-gradient mask + 6 M fp32 gradients in one RCCL all-reduce
 torch.cuda.synchronize()
-assert n == 1 and len(before) > 100
+assert n == 2 and len(before) > 100
+assert dict(net.named_parameters())["all_modules.0.W"].grad is None
 assert all(torch.equal(before[k], p.grad) for k, p in net.named_parameters() if k in before)   # mean over one rank = identity
 dist.barrier(); dist.destroy_process_group()
 print("RCCL_TRAIN_WORLD1_OK")

@@ -1102,7 +1102,7 @@ int use_load_weight_blob(use_handle* h, const char* path) {
     h->host_w.clear();
     h->weights_ready = true;
     h->sampler_set = false;
-    drop_graphs(h);
+    drop_graphs(h); plan_cache_clear(h);                     // parked plans hold time-embedding tables + graphs of the OLD weights
     return USE_OK;
 }
 

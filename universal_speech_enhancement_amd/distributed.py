@@ -86,12 +86,20 @@ def allreduce_gradients(params, bucket_bytes: int = 256 << 20, average: bool = T
     for the reference's ``training_step``, SGMSE_module.py:46-54 with trainer strategy ddp).  Gradients are packed into contiguous
     buckets of ``bucket_bytes`` (default 256 MB: NCSN++ large's 65 M fp32 gradients travel as ONE ring all-reduce - xGMI is
     point-to-point, a ring is bound per link, so few large messages beat DDP's 25 MB default), reduced in place and copied back.
-    Parameters without a gradient on this rank contribute zeros (every rank must call with the same parameter list).  Returns the
-    number of collectives issued (0 without a process group)."""
+    Parameters without a gradient on this rank contribute zeros; those without one on ANY rank are left alone (one small MAX all-reduce
+    of the has-gradient mask finds them; every rank must call with the same parameter list).  Returns the number of collectives issued
+    (0 without a process group)."""
     params = [p for p in params if p.requires_grad]
     if not dist.is_initialized() or not params:
         return 0
     world = dist.get_world_size()
+    # a parameter without a gradient on EVERY rank (frozen in effect: e.g. detached in the taped forward) keeps grad = None, as in
+    # single-process training - materialising zeros would let Adam's weight decay move it
+    has = torch.tensor([0 if p.grad is None else 1 for p in params], dtype=torch.int32, device=params[0].device)
+    dist.all_reduce(has, op=dist.ReduceOp.MAX)
+    params = [p for p, k in zip(params, has.tolist()) if k]
+    if not params:
+        return 1
     buckets, cur, cur_bytes = [], [], 0
     for p in params:
         nb = p.numel() * p.element_size()
@@ -118,4 +126,4 @@ def allreduce_gradients(params, bucket_bytes: int = 256 << 20, average: bool = T
             else:
                 p.grad.copy_(g)
             o += p.numel()
-    return len(buckets)
+    return len(buckets) + 1

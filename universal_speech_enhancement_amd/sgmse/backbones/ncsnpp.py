@@ -130,8 +130,9 @@ class NCSNpp(nn.Module):
 
     def load_weight_file(self, path: str, n_freq: int = 512, device=None):
         """Start from a packed weight file (``pack_checkpoint``; ``use_load_weight_blob``) instead of a state dict: the
-        module's own parameters are left untouched and no longer consulted -- until ``load_state_dict`` /
-        ``refresh_weights`` hands the module's parameters back to the engine."""
+        module's own parameters are left untouched (their random initialisation) and no longer consulted -- until ``load_state_dict`` /
+        ``refresh_weights`` hands the module's parameters back to the engine.  Training from this state is refused
+        (``forward_train`` raises): the packed file cannot be unpacked into parameters."""
         self._weight_file = str(path)
         self._engine = None
         self._engine_dirty = True
@@ -140,6 +141,15 @@ class NCSNpp(nn.Module):
     def refresh_weights(self):
         """Call after modifying parameters in place (``load_state_dict`` is tracked automatically)."""
         self._engine_dirty, self._weight_file = True, None
+
+    def requires_grad_(self, requires_grad: bool = True):
+        """``module.requires_grad_(True)`` is the documented way to enable training.  The Gaussian-Fourier projection ``all_modules.0.W``
+        stays frozen, as in the reference (``GaussianFourierProjection``: ``nn.Parameter(..., requires_grad=False)``, layerspp.py:35) -
+        an optimiser with weight decay would otherwise move the embedding frequencies under data-parallel training."""
+        super().requires_grad_(requires_grad)
+        if requires_grad and self.conditional and len(self.all_modules) and hasattr(self.all_modules[0], "W"):
+            self.all_modules[0].W.requires_grad_(False)
+        return self
 
     @property
     def trainable(self) -> bool:
@@ -157,7 +167,12 @@ class NCSNpp(nn.Module):
         if any(not p.is_cuda for p in P.values()):
             from ...hip_engine import UseHipError
             raise UseHipError("NCSN++ (HIP) training needs the parameters on the GPU (module.to('cuda')): there is no CPU implementation")
-        self._engine_dirty, self._weight_file = True, None
+        if self._weight_file is not None:
+            from ...hip_engine import UseHipError
+            raise UseHipError(f"the module's weights came from the packed file '{self._weight_file}' (load_weight_file): its parameters still hold "
+                              "their random initialisation, so training would silently discard the file - load a state dict "
+                              "(load_state_dict / pack_checkpoint's source checkpoint) before fine-tuning")
+        self._engine_dirty = True
         cd = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[self.train_precision]
         return ncsnpp_forward_train(P, x, time_cond, self.ch_mult, self.num_res_blocks, conditional=self.conditional,
                                     scale_by_sigma=self.scale_by_sigma, compute_dtype=cd)

@@ -77,10 +77,12 @@ class ScoreModel(SpectralGlue, nn.Module):
         x, y = batch["clean"], batch["perturbed"]
         y_denoised = batch.get("fake")
         # The reference feeds spec_fwd(stft(.)) of the target_len excerpt - exactly num_frames frames, NOT padded - to the network, whose
-        # six FIR down / up sampling stages only close for multiples of 64 frames.  _spectrogram() would zero-pad another count silently
+        # len(ch_mult) - 1 FIR down / up sampling stages only close for multiples of 2^(levels - 1) frames (64 for the 7-level NCSN++).  _spectrogram() would zero-pad another count silently
         # (extra frames in z, in the loss and in the network input): refuse it, as the reference's own forward pass fails there.
-        if self.num_frames % 64 != 0:
-            raise ValueError(f"train_step: num_frames={self.num_frames} is not a multiple of 64 frames (the excerpt's spectrogram must "
+        ch_mult = getattr(self.score_net, "ch_mult", None)              # backbones without resampling stages take any frame count
+        mult = 1 << (len(ch_mult) - 1) if ch_mult else 1
+        if self.num_frames % mult != 0:
+            raise ValueError(f"train_step: num_frames={self.num_frames} is not a multiple of {mult} frames (the excerpt's spectrogram must "
                              "enter the network unpadded, reference model_wrapper.py:168-171)")
         current_len = x.size(-1)
         pad = max(self.target_len - current_len, 0)
