@@ -107,7 +107,7 @@ def test_fused_langevin_on_split_batches_16bit(sd_np, prec):
         assert err < tol, (prec, b, err)
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", lp.fwd_bound("bf16")), ("fp16", lp.fwd_bound("fp16"))])   # 16-bit: the reference's own autocast error
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", lp.fwd_bound("bf16", 1.25)), ("fp16", lp.fwd_bound("fp16", 1.25))])   # 16-bit: 1.25 x the reference's own autocast error (other inputs than the fixture's)
 def test_quiet_and_silent_items_through_one_score_evaluation(sd_np, prec, tol):
     """Item 0 ordinary, item 1 the same signal x 1e-3, item 2 all zeros (x and Y): per-item error against the CPU oracle.
     (the fixed-point sums of squares used to round a quiet item's partial sums to zero.)"""

@@ -25,6 +25,11 @@ namespace use {
 constexpr int V4_TW = 32, V4_TH = 16;             // tile: 16 rows x 32 columns
 constexpr int V4_HW = V4_TW + 2, V4_HH = V4_TH + 2;
 constexpr int V4_BN = 128;
+#ifdef USE_HIP_XF_LEGACY            /* A/B builds only: the round 1-3 form (transform left to the compiler's scheduling) */
+constexpr bool V4_XF_LEGACY = true;
+#else
+constexpr bool V4_XF_LEGACY = false;
+#endif
 
 template <typename TIN, typename TOUT, int CK, bool ACT>
 __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     static_assert(PARTS == 4 && PIECE_ITERS == 5 && BN * PARTS == 512, "v4 staging layout");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [2][HALO_BYTES] halo tiles, [2][W_BYTES] weight slabs, [512][16] dummy slots (threads without a piece)
+    // [2][HALO_BYTES] halo tiles, [2][W_BYTES] weight slabs, [512] float2 GroupNorm affine, [2][5][512] int piece tables
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z;
     int tile = blockIdx.x;                                   // XCD-aware order: contiguous band of tiles per XCD
@@ -67,16 +72,25 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         addv[j] = add;
     }
 
-#ifdef USE_HIP_TRACE_BUILD   /* bring-up: lane 0 of waves 0 and 4 of workgroup 0 stamp the cycle counter at coarse boundaries */
-    const bool tracing = p.trace != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave & 3) == 0;
+#ifdef USE_HIP_TRACE_BUILD   /* bring-up: lane 0 of waves 0 and 4 of workgroup p.dbg of item 0 stamp the cycle counter at phase boundaries */
+    // Stamps go to LDS (behind everything else, 2 x 124 x 16 B) and are copied out at the end: a global store per stamp sits in the
+    // VMEM queue of the very waits it is meant to observe (round 4: that form inflated the LDS phases 2-3x).
+    const bool tracing = p.trace != nullptr && (int)(blockIdx.x + gridDim.x * blockIdx.z) == p.dbg && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0;
     int trace_n = 0;
+    unsigned long long* const trace_lds = reinterpret_cast<unsigned long long*>(smem + 147456) + (wave >> 2) * 248;
 #define V4_STAMP(ID)                                                                                   \
-    if (tracing && trace_n < 120) {                                                                    \
-        p.trace[(wave >> 2) * 256 + 2 * trace_n] = (unsigned long long)(ID);                           \
-        p.trace[(wave >> 2) * 256 + 2 * trace_n + 1] = __builtin_readcyclecounter(); ++trace_n;        \
+    if (tracing && trace_n < 124) {                                                                    \
+        trace_lds[2 * trace_n] = (unsigned long long)(ID);                                             \
+        trace_lds[2 * trace_n + 1] = __builtin_readcyclecounter(); ++trace_n;                          \
     }
+#define V4_TRACE_FORCE(R) asm volatile("" :: "v"((R).x), "v"((R).y), "v"((R).z), "v"((R).w));
+#define V4_PSTAMP_C(C_, ID) if ((C_) >= 1 && (C_) <= 2) { V4_STAMP(ID) }
+#define V4_PSTAMP(ID) if (c >= 1 && c <= 2) { V4_STAMP(ID) }   /* per-phase stamps of the second and third K chunk: 1xx = end of MFMA(T), 2xx = end of LDS(T) (before the barrier) */
 #else
 #define V4_STAMP(ID)
+#define V4_PSTAMP(ID)
+#define V4_PSTAMP_C(C_, ID)
+#define V4_TRACE_FORCE(R)
 #endif
     V4_STAMP(1)
     f32x16 acc[TM][TN];
@@ -96,22 +110,35 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         b_base[j] = 2 * HALO_BYTES + (j * 32 + (lane & 31)) * ROWB + (lane >> 5) * MF::KPL * (int)sizeof(TIN);
 
     // ---- segment-0 halo pieces: this thread's piece j (0..4) of every chunk --------------------------------------------
-    int ppix[PIECE_ITERS], pdst[PIECE_ITERS]; unsigned pmask[PIECE_ITERS];
+    // Per piece: the pixel offset of its global load and the byte offset of its LDS row - kept in two LDS tables (read back by the
+    // owning thread only), not in registers: the register file is what limits the depth of the load pipeline below.  Pieces outside
+    // the image (zero padding, applied AFTER the activation) are zeroed ONCE here in both halo buffers and from then on written into
+    // the unused 16-byte tail of their 80-byte LDS row: no per-piece mask in the main loop.
+    constexpr int COEF_OFF = MAIN_BYTES;                     // [Ctot <= 512] float2
+    constexpr int TAB_OFF = COEF_OFF + 512 * 8;              // [2][PIECE_ITERS][512] int
+    int* const pix_tab = reinterpret_cast<int*>(smem + TAB_OFF);
+    int* const dst_tab = pix_tab + PIECE_ITERS * 512;
 #pragma unroll
     for (int j = 0; j < PIECE_ITERS; ++j) {
         const int idx = j * 512 + tid;
-        const int pix = idx / PARTS;
+        const int pix = idx < NPIECE ? idx / PARTS : idx / PARTS - V4_HH * V4_HW;     // (threads without a fifth piece: a pad slot of row 0)
         const int hy = pix / V4_HW, hx = pix - hy * V4_HW;
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         const bool inb = idx < NPIECE && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        ppix[j] = inb ? gy * p.W + gx : 0;                  // pixel offset inside the item's image (the item offset sits in the buffer base)
-        pmask[j] = inb ? 0xffffffffu : 0u;
-        pdst[j] = idx < NPIECE ? hy * HPITCH + hx * ROWB + part * 16 : -1;
+        int pp = inb ? gy * p.W + gx : 0;                    // pixel offset inside the item's image (the item offset sits in the buffer base)
+#ifdef USE_HIP_ABLATE
+        if (p.dbg & 1) pp = idx & 127;                       // timing only: every halo load hits the same 32 KB (cache-resident): prices the exposed load latency
+#endif
+        const int row = hy * HPITCH + hx * ROWB;
+        if (idx < NPIECE && !inb) {
+            *reinterpret_cast<uint4*>(smem + row + part * 16) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(smem + HALO_BYTES + row + part * 16) = make_uint4(0, 0, 0, 0);
+        }
+        pix_tab[idx] = pp;
+        dst_tab[idx] = inb ? row + part * 16 : row + CK * (int)sizeof(TIN);
     }
-    const int dummy_off = MAIN_BYTES + tid * 16;
     // GroupNorm affine (a, b) of every input channel of this item in LDS: finalised here from the producers' totals (or copied
     // from a coefficient array, or the identity) - no separate finalize launch, and the per-chunk reads are LDS reads
-    constexpr int COEF_OFF = MAIN_BYTES + 512 * 16;
     float2* const coef_lds = reinterpret_cast<float2*>(smem + COEF_OFF);   // filled in the prologue, behind the first loads
     float ca[VEC], cb[VEC];                                  // GroupNorm affine of the chunk being staged
     auto load_coef = [&](int chunk) {
@@ -160,38 +187,53 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     // weights of iteration (chunk CC, tap TT) -> R ; TT may run past 8 (wraps into the next chunk)
 #define V4_LOAD_W(CC, TT, R)                                                                                         \
     {                                                                                                                \
-        const int cw_ = (TT) > 8 ? (CC) + 1 : (CC);                                                                  \
-        const int tw_ = (TT) > 8 ? (TT)-9 : (TT);                                                                    \
-        if (cw_ < nchunks) R = buf_ld(p.wb, wvoff, (unsigned)(tw_ * nchunks + cw_) * slab_b + n0_b);                 \
+        const int cw0_ = (TT) > 8 ? (CC) + 1 : (CC);                                                                 \
+        const int cw_ = cw0_ < nchunks ? cw0_ : nchunks - 1; /* past the end: a harmless re-load (NO branch: a load on one  */ \
+        const int tw_ = (TT) > 8 ? (TT)-9 : (TT);            /* control-flow path only turns hipcc's next wait into vmcnt(0)) */ \
+        R = buf_ld(p.wb, wvoff, (unsigned)(tw_ * nchunks + cw_) * slab_b + n0_b);                                    \
     }
 #define V4_STORE_W(BUF, R) { *reinterpret_cast<uint4*>(smem + (BUF)*W_BYTES + wdst) = R; }
 
     // ---- prologue: chunk 0 halo (synchronous), weights of iterations 0 and 1 -------------------------------------------
-    uint4 wa = make_uint4(0, 0, 0, 0);
+    // Load pipeline.  Round 4 measurement: with the halo loads served from cache the kernel ran 7.5 % faster, i.e. it was waiting
+    // for memory - a piece was loaded in LDS(k) and waited for ("parked") at the start of LDS(k+1), and the wait for the weight
+    // slab issued behind it in LDS(k) forced it to have arrived by then anyway (VMEM returns in order).  Now: halo piece k of the
+    // next chunk is issued in LDS(k) into register set k & 1 and first touched by the transform behind the MFMAs of MFMA(k+1) (the
+    // wait sits in front of that phase's first MFMA: one and a half iterations of cover, no parking copy); the transformed piece is
+    // stored at the end of the same phase (the other halo buffer: nobody reads it during this chunk).  The weight slab of iteration n
+    // (L2-resident: every workgroup reads the same 295 KB) is issued in LDS(n-2) BEFORE that phase's halo load, stored in LDS(n-1) -
+    // its wait (vmcnt(1)) leaves the younger, slower halo load in flight - and read in LDS(n).  Two full iterations of cover (three
+    // halo sets, consumption in MFMA(k+2)) do not fit the 256 registers of a wave: 41 spills.
+    uint4 wS, hL[2];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    wS = hL[0] = hL[1] = zero4;
     {
-        uint4 w0 = wa, raw[PIECE_ITERS];
+        uint4 w0 = zero4, raw[PIECE_ITERS];
         V4_LOAD_W(0, 0, w0);
-        V4_LOAD_W(0, 1, wa);                                 // stored by LDS(0)
+        V4_LOAD_W(0, 1, wS);                                 // stored by LDS(0)
 #pragma unroll
-        for (int j = 0; j < PIECE_ITERS; ++j) raw[j] = src_ld0(0, ppix[j]);
+        for (int j = 0; j < PIECE_ITERS; ++j) raw[j] = src_ld0(0, pix_tab[j * 512 + tid]);
         gn_fill_table(coef_lds, p, b, Ctot, tid, 512);       // while the halo / weight loads are in flight
         __syncthreads();                                     // coef_lds complete
         load_coef(0);
         V4_STORE_W(0, w0);
 #pragma unroll
         for (int j = 0; j < PIECE_ITERS; ++j)
-            *reinterpret_cast<uint4*>(smem + (pdst[j] >= 0 ? pdst[j] : dummy_off)) = stage_transform<TIN, ACT>(raw[j], pmask[j], ca, cb);
+            *reinterpret_cast<uint4*>(smem + dst_tab[j * 512 + tid]) = stage_transform<TIN, ACT>(raw[j], 0xffffffffu, ca, cb);
     }
 
     typename MF::frag af[KSTEPS][TM], bf[KSTEPS][TN];
-    uint4 hL = wa, hT = wa, t0 = wa;                         // piece in flight, piece being transformed, transformed piece
-    // Per (chunk CC, tap T), T a literal.  Piece k (0..4) of chunk CC+1: global load issued in LDS(k) -> parked in plain
-    // registers in LDS(k+1) -> GroupNorm+SiLU on the VALU behind the MFMAs of MFMA(k+1) -> written in LDS(k+2).
+    int dst_ = 0;                                            // LDS address of the piece the next MFMA phase transforms
+#define V4_XF_PHASE(T) ((T) >= 1 && (T) < PIECE_ITERS + 1)   /* MFMA(T) carries the transform of piece T - 1 */
 #define V4_LDS(CC, T)                                                                                                \
     {                                                                                                                \
         const int cc_ = (CC);                                                                                        \
         const int par_ = cc_ & 1;                            /* halo buffer this chunk reads; it parity = par_ ^ (T&1) */ \
-        const bool next_ = cc_ + 1 < nchunks;                                                                        \
+        const int cn_ = cc_ + 1 < nchunks ? cc_ + 1 : cc_;   /* chunk being staged (last chunk: itself again, results unused - */ \
+        int pix_ = 0;                                        /* everything below is unconditional, see V4_LOAD_W)             */ \
+        /* table entries first: they return ahead of the fragments */                                                \
+        if ((T) < PIECE_ITERS) pix_ = pix_tab[((T) < PIECE_ITERS ? (T) : 0) * 512 + tid];                            \
+        if (V4_XF_PHASE(T)) dst_ = dst_tab[(V4_XF_PHASE(T) ? (T)-1 : 0) * 512 + tid];                                \
         {                                                                                                            \
             const char* ha_ = smem + par_ * HALO_BYTES + ((T) / 3) * HPITCH + ((T) % 3) * ROWB;                      \
             const char* wbuf_ = smem + (par_ ^ ((T)&1)) * W_BYTES;                                                   \
@@ -201,37 +243,43 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
             }                                                                                                        \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if ((T) >= 2 && (T) < PIECE_ITERS + 2 && next_) {                                                            \
-            constexpr int k_ = (T) >= 2 && (T) < PIECE_ITERS + 2 ? (T)-2 : 0;                                        \
-            *reinterpret_cast<uint4*>(smem + (pdst[k_] >= 0 ? (par_ ^ 1) * HALO_BYTES + pdst[k_] : dummy_off)) = t0;  \
+        if (V4_XF_PHASE(T)) dst_ += (par_ ^ 1) * HALO_BYTES; /* where MFMA(T) puts its transformed piece */          \
+        V4_STORE_W((par_ ^ ((T)&1)) ^ 1, wS);                                                                        \
+        V4_LOAD_W(cc_, (T) + 2, wS);                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                   /* the slab load stays older than the halo load */      \
+        if ((T) < PIECE_ITERS) {                                                                                     \
+            if ((T) == 0) load_coef(cn_);                                                                            \
+            hL[(T)&1] = src_ld0(cn_, pix_);                                                                          \
         }                                                                                                            \
-        if ((T) < 8 || next_) V4_STORE_W((par_ ^ ((T)&1)) ^ 1, wa);                                                  \
-        if ((T) >= 1 && (T) < PIECE_ITERS + 1) {                                                                     \
-            /* the piece loaded one iteration ago has landed: park it in plain registers so that the MFMA-phase    */ \
-            /* transform carries no vmcnt wait on this phase's fresh loads                                          */ \
-            hT = hL;                                                                                                 \
-            asm volatile("" : "+v"(hT.x), "+v"(hT.y), "+v"(hT.z), "+v"(hT.w));                                       \
-        }                                                                                                            \
-        if ((T) < PIECE_ITERS && next_) {                                                                            \
-            if ((T) == 0) load_coef(cc_ + 1);                                                                        \
-            constexpr int k_ = (T) < PIECE_ITERS ? (T) : 0;                                                          \
-            hL = src_ld0(cc_ + 1, ppix[k_]);                                                                         \
-        }                                                                                                            \
-        V4_LOAD_W(cc_, (T) + 2, wa);                                                                                 \
     }
 #define V4_MFMA(CC, T)                                                                                               \
     {                                                                                                                \
-        _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk)                                                        \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                           \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);  \
-        if ((T) >= 1 && (T) < PIECE_ITERS + 1) {             /* unconditional at run time: same basic block as the MFMAs */ \
-            constexpr int k_ = (T) >= 1 && (T) < PIECE_ITERS + 1 ? (T)-1 : 0;                                        \
-            t0 = stage_transform<TIN, ACT>(hT, pmask[k_], ca, cb);                                                      \
-            asm volatile("" : "+v"(t0.x), "+v"(t0.y), "+v"(t0.z), "+v"(t0.w));   /* materialise here, not at the ds_write */ \
-            _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                         \
-                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * KSTEPS / 16, 0);   /* MFMA  */                 \
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                       /* 3 VALU  */               \
-                __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);                       /* 1 TRANS */               \
+        if constexpr (sizeof(TIN) == 2 && !V4_XF_LEGACY) {                                                           \
+            if (V4_XF_PHASE(T)) {                            /* unconditional at run time: same basic block as the MFMAs */ \
+                /* 16 MFMAs, slice g of the GroupNorm + SiLU transform of one halo piece behind MFMA g, one asm statement */ \
+                /* each (use_device.h, XfAsm: left to itself hipcc runs the transform with the matrix pipe idle)          */ \
+                V4_PSTAMP_C(CC, 300 + (T))                        /* trace builds: 3xx -> 4xx = the exposed wait for the halo piece */ \
+                V4_TRACE_FORCE(hL[(V4_XF_PHASE(T) ? (T)-1 : 0) & 1])                                                 \
+                V4_PSTAMP_C(CC, 400 + (T))                                                                               \
+                const uint4 t0 = mfma16_with_transform<TIN, ACT>(acc, af, bf, hL[(V4_XF_PHASE(T) ? (T)-1 : 0) & 1], ca, cb); \
+                *reinterpret_cast<uint4*>(smem + dst_) = t0; /* the other halo buffer: nobody reads it during this chunk */ \
+            } else {                                                                                                 \
+                _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk)                                                \
+                    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+                        _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);  \
+            }                                                                                                        \
+        } else {                                                                                                     \
+            _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk)                                                    \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                       \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);  \
+            if (V4_XF_PHASE(T)) {                                                                                    \
+                const uint4 t0 = stage_transform<TIN, ACT>(hL[(V4_XF_PHASE(T) ? (T)-1 : 0) & 1], 0xffffffffu, ca, cb); \
+                *reinterpret_cast<uint4*>(smem + dst_) = t0;                                                         \
+                _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                     \
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * KSTEPS / 16, 0);   /* MFMA  */             \
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                       /* 3 VALU  */           \
+                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);                       /* 1 TRANS */           \
+                }                                                                                                    \
             }                                                                                                        \
         }                                                                                                            \
     }
@@ -241,6 +289,9 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     //   G0:    LDS(0)  MFMA(0)  LDS(1)  MFMA(1)  LDS(2)
     //   G1:     --     LDS(0)  MFMA(0)  LDS(1)  MFMA(1)
 #define V4_BAR() { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
+    // rendezvous at the end of an MFMA phase: the only LDS operation a wave may have in flight there is the store of the piece it has
+    // just transformed, which nobody reads before the next chunk (several full barriers later) - no lgkmcnt wait in front of it
+#define V4_BAR_M() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
     V4_STAMP(2)
     V4_BAR();
     V4_STAMP(3)
@@ -248,30 +299,31 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         V4_LDS(0, 0)
         V4_BAR();
         for (int c = 0; c < nchunks; ++c) {
-#define V4_G0_STEP(T) V4_MFMA(c, T) V4_BAR(); V4_LDS(c, (T) + 1) V4_BAR();
+#define V4_G0_STEP(T) V4_MFMA(c, T) V4_PSTAMP(100 + (T)) V4_BAR_M(); V4_LDS(c, (T) + 1) V4_PSTAMP(200 + (T) + 1) V4_BAR();
             V4_G0_STEP(0) V4_G0_STEP(1) V4_G0_STEP(2) V4_G0_STEP(3) V4_G0_STEP(4) V4_G0_STEP(5) V4_G0_STEP(6) V4_G0_STEP(7)
 #undef V4_G0_STEP
             V4_MFMA(c, 8)
-            V4_BAR();
-            if (c + 1 < nchunks) V4_LDS(c + 1, 0)
+            V4_BAR_M();
+            if (c + 1 < nchunks) V4_LDS(c + 1, 0)           // (uniform; the last chunk has nothing left to read)
             V4_BAR();
         }
     } else {
         V4_BAR();
         for (int c = 0; c < nchunks; ++c) {
-#define V4_G1_STEP(T) V4_LDS(c, T) V4_BAR(); V4_MFMA(c, T) V4_BAR();
+#define V4_G1_STEP(T) V4_LDS(c, T) V4_PSTAMP(200 + (T)) V4_BAR(); V4_MFMA(c, T) V4_PSTAMP(100 + (T)) V4_BAR_M();
             V4_G1_STEP(0) V4_G1_STEP(1) V4_G1_STEP(2) V4_G1_STEP(3) V4_G1_STEP(4) V4_G1_STEP(5) V4_G1_STEP(6) V4_G1_STEP(7) V4_G1_STEP(8)
 #undef V4_G1_STEP
         }
     }
 #undef V4_BAR
+#undef V4_BAR_M
 #undef V4_LDS
 #undef V4_LOAD_W
 
     V4_STAMP(4)
     // ---- segment 1: the fused 1x1 shortcut: raw centre pixels; double-buffered, one barrier per iteration ---------------
     if (nchunks2 > 0) {
-        uint4 r0, r1, r2, r3; unsigned m0, m1, m2, m3;
+        uint4 r0, r1, r2, r3, wa; unsigned m0, m1, m2, m3;
         const unsigned slab2_b = (unsigned)(p.cout_pad * CK) * (unsigned)sizeof(TIN);
 #define V4_SC_LOAD(C2)                                                                                        \
         {                                                                                                     \
@@ -304,7 +356,13 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     V4_STAMP(5)
     __syncthreads();                                         // the epilogue re-uses the LDS
     V4_STAMP(6)
+#ifdef USE_HIP_TRACE_BUILD
+    if (tracing) {                                           // (the epilogue's own stamps 7 / 8 are not recorded in this form)
+        for (int i = 0; i < 2 * trace_n; ++i) p.trace[(wave >> 2) * 256 + i] = trace_lds[i];
+    }
+#endif
 #undef V4_MFMA
+#undef V4_XF_PHASE
 #undef V4_STORE_W
 
     // ------------------------------ epilogue: per-wave LDS transpose, 16-byte I/O ------------------------------------------
@@ -432,9 +490,14 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
 template <typename TIN, typename TOUT, int CK, bool ACT>
 static void v4_launch_t(const ConvArgs& a, hipStream_t s) {
     constexpr int ROWB = CK * (int)sizeof(TIN) + 16;
-    constexpr int MAIN = 2 * V4_HH * V4_HW * ROWB + 2 * V4_BN * ROWB + 512 * 16 + 512 * 8;
+    constexpr int MAIN = 2 * V4_HH * V4_HW * ROWB + 2 * V4_BN * ROWB + 512 * 8 + 2 * 5 * 512 * 4;   // halo + weight buffers, GroupNorm table, piece tables
     constexpr int EPI = 8 * 32 * (V4_BN + 4) * 4 + 8 * V4_BN * 2 * 4;
+#ifdef USE_HIP_TRACE_BUILD
+    constexpr int SMEM = 147456 + 2 * 248 * 8;               // + the stamp buffers
+#else
     constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
+#endif
+    static_assert(MAIN <= 147456 && EPI <= 147456 && SMEM <= 163840, "LDS budget");
     static bool attr_set = false;
     auto kern = conv_v4_kernel<TIN, TOUT, CK, ACT>;
     if (!attr_set) {

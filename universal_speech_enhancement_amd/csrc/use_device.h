@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <utility>
 
 namespace use {
 
@@ -117,6 +118,79 @@ template <> struct Mfma<float> {
     DEVI static frag ld(const char* p) { return *reinterpret_cast<const float*>(p); }
     DEVI static f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 };
+
+// ---------------------------------------------------------------------------------------------------------
+// 16 MFMAs carrying the GroupNorm + SiLU transform of one 16-bit halo piece, as FIVE asm statements: the only way to keep the
+// transform inside the MFMAs' shadow.  Round 4 findings behind this form:
+//  * hipcc emits a phase of "16 MFMAs + transform of one piece" as 8 MFMAs, the whole ~60-instruction VALU block (matrix pipe idle),
+//    8 MFMAs - whatever sched_group_barrier / sched_barrier asks for: MFMAs and transform are side-effect-free and are placed before
+//    the machine scheduler ever sees the barriers.  Such a phase took ~860 cycles against 512 of MFMA issue.  Volatile asm keeps its order.
+//  * behind back-to-back v_mfma_f32_32x32x16 one wave issues 4 VALU instructions per MFMA for free (scripts/microbench/mfma_filler:
+//    513 cycles bare, 529 with 60 instructions at <= 4 per gap, 573 at 5 per gap over the last 12 gaps, 653 at 7-8 over the last 8;
+//    dependent neighbours cost: one element's chain per gap 545) - scalar f32 ops, two independent chains (the low and high half of
+//    a dword) interleaved so that no instruction reads its predecessor's result.
+//  * the halo piece arrives late: the first four MFMAs of the phase carry nothing, so the wait for the piece (which hipcc puts in front
+//    of the first statement that reads it) sits 128+ cycles into the phase, and the transform runs 5 per gap behind the other twelve.
+// Per dword (two elements, l / h):  x = unpack, u = a x + b, x = -log2(e) u, x = exp2(x), x = 1 + x, x = rcp(x), u = u x, pack(u_l, u_h):
+// the operations of stage_transform in the same order per element: bit-identical results.
+// Hazards the compiler cannot see inside asm: a transcendental's result is read two instructions later (one wait state needed); an
+// MFMA's accumulator is next touched 8 MFMAs later as SrcC = vDst of the same shape (no wait states needed); the epilogue's VALU
+// reads of the accumulators come after compiler-visible MFMAs (the last phase of a chunk carries no piece).
+// ---------------------------------------------------------------------------------------------------------
+template <typename TIN> struct XfAsm;
+#define USE_XF_ASM_STRINGS(T, MFMA, LO, HI, PK)                                                                          \
+    template <> struct XfAsm<T> {                                                                                        \
+        typedef typename Mfma<T>::frag frag;                                                                             \
+        DEVI static void bare4(f32x16& c0, f32x16& c1, f32x16& c2, f32x16& c3, const frag& a, const frag& b0, const frag& b1, const frag& b2, const frag& b3) { \
+            asm volatile(MFMA " %0, %4, %5, %0\n\t" MFMA " %1, %4, %6, %1\n\t" MFMA " %2, %4, %7, %2\n\t" MFMA " %3, %4, %8, %3" \
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));          \
+        }                                                                                                                \
+        /* three MFMAs (accumulators c0..c2 with operands (a0,b0) (a1,b1) (a2,b2)) + the transform of dword d (in place) */ \
+        template <bool ACT>                                                                                              \
+        DEVI static void dword3(f32x16& c0, f32x16& c1, f32x16& c2, const frag& a0, const frag& a1, const frag& a2, const frag& b0, const frag& b1, \
+                                const frag& b2, unsigned& d, float al, float bl, float ah, float bh) {                   \
+            float xl, xh, ul, uh;                                                                                        \
+            if (ACT)                                                                                                     \
+                asm volatile(MFMA " %0, %8, %11, %0\n\t"                                                                 \
+                             LO("%4", "%3") "\n\t" HI("%5", "%3") "\n\tv_fma_f32 %6, %4, %14, %15\n\tv_fma_f32 %7, %5, %16, %17\n\tv_mul_f32 %4, 0xbfb8aa3b, %6\n\t" \
+                             MFMA " %1, %9, %12, %1\n\t"                                                                 \
+                             "v_mul_f32 %5, 0xbfb8aa3b, %7\n\tv_exp_f32 %4, %4\n\tv_exp_f32 %5, %5\n\tv_add_f32 %4, 1.0, %4\n\tv_add_f32 %5, 1.0, %5\n\t" \
+                             MFMA " %2, %10, %13, %2\n\t"                                                                \
+                             "v_rcp_f32 %4, %4\n\tv_rcp_f32 %5, %5\n\tv_mul_f32 %6, %6, %4\n\tv_mul_f32 %7, %7, %5\n\t" PK("%3", "%6", "%7") \
+                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(d), "=&v"(xl), "=&v"(xh), "=&v"(ul), "=&v"(uh)                         \
+                             : "v"(a0), "v"(a1), "v"(a2), "v"(b0), "v"(b1), "v"(b2), "v"(al), "v"(bl), "v"(ah), "v"(bh));               \
+            else                                                                                                         \
+                asm volatile(MFMA " %0, %8, %11, %0\n\t"                                                                 \
+                             LO("%4", "%3") "\n\t" HI("%5", "%3") "\n\tv_fma_f32 %6, %4, %14, %15\n\tv_fma_f32 %7, %5, %16, %17\n\t" \
+                             MFMA " %1, %9, %12, %1\n\t"                                                                 \
+                             MFMA " %2, %10, %13, %2\n\t" PK("%3", "%6", "%7")                                           \
+                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(d), "=&v"(xl), "=&v"(xh), "=&v"(ul), "=&v"(uh)                         \
+                             : "v"(a0), "v"(a1), "v"(a2), "v"(b0), "v"(b1), "v"(b2), "v"(al), "v"(bl), "v"(ah), "v"(bh));               \
+        }                                                                                                                \
+    };
+#define USE_XF_BF16_LO(D, S) "v_lshlrev_b32 " D ", 16, " S
+#define USE_XF_BF16_HI(D, S) "v_and_b32 " D ", 0xffff0000, " S
+#define USE_XF_BF16_PK(D, A, B) "v_cvt_pk_bf16_f32 " D ", " A ", " B
+#define USE_XF_F16_LO(D, S) "v_cvt_f32_f16 " D ", " S
+#define USE_XF_F16_HI(D, S) "v_cvt_f32_f16_sdwa " D ", " S " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
+#define USE_XF_F16_PK(D, A, B) "v_cvt_pk_f16_f32 " D ", " A ", " B
+USE_XF_ASM_STRINGS(__bf16, "v_mfma_f32_32x32x16_bf16", USE_XF_BF16_LO, USE_XF_BF16_HI, USE_XF_BF16_PK)
+USE_XF_ASM_STRINGS(_Float16, "v_mfma_f32_32x32x16_f16", USE_XF_F16_LO, USE_XF_F16_HI, USE_XF_F16_PK)
+#undef USE_XF_ASM_STRINGS
+
+// 16 MFMAs (acc[i][j] += a[kk][i] b[kk][j], MFMA g = (kk * 2 + i) * 4 + j: the 2 x 4 x 2 register tile of conv_v4 / conv_v2) carrying
+// the transform of one 16-byte piece `raw` -> returned
+template <typename TIN, bool ACT, typename ACC, typename AF, typename BF>
+DEVI uint4 mfma16_with_transform(ACC& acc, const AF& af, const BF& bf, const uint4 raw, const float (&ca)[8], const float (&cb)[8]) {
+    typedef XfAsm<TIN> X;
+    unsigned d[4] = {raw.x, raw.y, raw.z, raw.w};
+    X::bare4(acc[0][0], acc[0][1], acc[0][2], acc[0][3], af[0][0], bf[0][0], bf[0][1], bf[0][2], bf[0][3]);                          // g = 0 .. 3
+    X::template dword3<ACT>(acc[1][0], acc[1][1], acc[1][2], af[0][1], af[0][1], af[0][1], bf[0][0], bf[0][1], bf[0][2], d[0], ca[0], cb[0], ca[1], cb[1]);   // 4 .. 6
+    X::template dword3<ACT>(acc[1][3], acc[0][0], acc[0][1], af[0][1], af[1][0], af[1][0], bf[0][3], bf[1][0], bf[1][1], d[1], ca[2], cb[2], ca[3], cb[3]);   // 7 .. 9
+    X::template dword3<ACT>(acc[0][2], acc[0][3], acc[1][0], af[1][0], af[1][0], af[1][1], bf[1][2], bf[1][3], bf[1][0], d[2], ca[4], cb[4], ca[5], cb[5]);   // 10 .. 12
+    X::template dword3<ACT>(acc[1][1], acc[1][2], acc[1][3], af[1][1], af[1][1], af[1][1], bf[1][1], bf[1][2], bf[1][3], d[3], ca[6], cb[6], ca[7], cb[7]);   // 13 .. 15
+    return make_uint4(d[0], d[1], d[2], d[3]);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // GroupNorm statistics: producers add their per-channel partial sums into [B][C][2] 64-bit fixed-point totals (integer

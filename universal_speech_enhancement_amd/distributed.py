@@ -55,7 +55,13 @@ def shard_list(items: Sequence, rank: int, world: int) -> List:
 def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     """In-place broadcast of a contiguous byte tensor (the packed weights) from ``src`` to every rank."""
     if dist.is_initialized():                               # (world size 1 included: the call path of the N-GPU run)
-        dist.broadcast(blob, src=src)
+        if blob.is_cuda and dist.get_backend() == "gloo":    # gloo moves host memory: stage the blob (tests: two ranks sharing one GPU)
+            host = blob.cpu()
+            dist.broadcast(host, src=src)
+            if dist.get_rank() != src:
+                blob.copy_(host)
+        else:
+            dist.broadcast(blob, src=src)
     return blob
 
 
