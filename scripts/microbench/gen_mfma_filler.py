@@ -62,6 +62,17 @@ def pattern(name):
         per = (len(seq) + n - 1) // n
         for i, op in enumerate(seq):
             gaps[min(first + i // per, 16)].append(op)
+    elif name in ("lds8", "lds8_vm"):            # the one-wave-per-SIMD step of conv_v9: dword-linear transform + 8 fragment reads
+        for q in range(4):                       # (+ 1 buffer load and 1 LDS store of a staged piece) behind 16 MFMAs
+            lo, hi = chain(2 * q, q, 0), chain(2 * q + 1, q, 1)
+            il = [op for pair in zip(lo, hi) for op in pair]
+            gaps[4 * q] += il[0:4]; gaps[4 * q + 1] += il[4:8]; gaps[4 * q + 2] += il[8:12]; gaps[4 * q + 3] += il[12:14]
+            gaps[4 * q + 4] += [f"v_cvt_pk_bf16_f32 %[d{q}], %[x{4*q+1}], %[x{4*q+3}]"]
+        for r in range(8):                      # issued early in the phase, waited for at the start of the NEXT one (as the frags of
+            gaps[r].append(f"ds_read_b128 %[f{r % 4}], %[la] offset:{r * 5120}")   # the next half-step would be)
+        if name == "lds8_vm":
+            gaps[9].append("buffer_load_dwordx4 %[f3], %[va], %[rs], 0 offen")
+            gaps[12].append("ds_write_b128 %[la], %[f2] offset:40960")
     elif name == "pk":                           # packed f32 ops on the (lo, hi) pair
         for q in range(4):
             X, Y = f"%[p{2*q}]", f"%[p{2*q+1}]"      # 64-bit pairs
@@ -83,6 +94,8 @@ def pattern(name):
     else:
         raise SystemExit(name)
     lines = []
+    if name.startswith("lds8"):
+        lines.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
     for g in range(16):
         lines.append(MFMA.format(i=g % 8))
         lines += gaps[g]
@@ -90,7 +103,7 @@ def pattern(name):
     return lines
 
 
-PATTERNS = ["bare", "serial", "dword", "dword_nop", "late12", "late8", "late6"]
+PATTERNS = ["bare", "dword", "late12"]
 out = []
 out.append('''// GENERATED by gen_mfma_filler.py - do not edit.  hipcc --offload-arch=gfx950 -O3 mfma_filler.hip -o mfma_filler
 #include <hip/hip_runtime.h>
@@ -108,7 +121,7 @@ for p in PATTERNS:
     # named accumulators: acc0..acc7 operands are positional 0..7 -> use names
     body = body
     out.append(f'''
-template <int LDSW> __global__ __launch_bounds__(512) void k_{p}(unsigned long long* out, float* sink, int iters) {{
+template <int LDSW> __global__ __launch_bounds__(512) void k_{p}(unsigned long long* out, float* sink, int iters, void* gsrc) {{
     __shared__ __attribute__((aligned(16))) char lds[65536];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x16 acc0 = {{}}, acc1 = {{}}, acc2 = {{}}, acc3 = {{}}, acc4 = {{}}, acc5 = {{}}, acc6 = {{}}, acc7 = {{}};
@@ -118,14 +131,24 @@ template <int LDSW> __global__ __launch_bounds__(512) void k_{p}(unsigned long l
     for (int i = 0; i < 16; ++i) x[i] = 0.01f * (lane + i);
     for (int i = 0; i < 4; ++i) d[i] = 0x3f803f80u + lane * 65537u * (i + 1);
     float c0 = 0.5f, c1 = 0.25f;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 f0 = {{}}, f1 = {{}}, f2 = {{}}, f3 = {{}};
+    const unsigned la = lane * 80, va = (threadIdx.x + blockIdx.x * 512) * 16;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gsrc, 0, 0x7fffffff, 0x00020000);
     reinterpret_cast<float*>(lds)[threadIdx.x] = 1.f;
     __syncthreads();
     unsigned long long t0 = 0, t1 = 0;
-    if (LDSW && wave >= 4) {{                  // partner waves (one per SIMD): an LDS phase's traffic in a loop, no barriers
-        float4 s = {{}};
+    if (LDSW && wave >= 4) {{                  // partner waves (one per SIMD): an LDS phase's traffic per ~500 cycles, no barriers
+        float4 s = {{}};                        // LDSW = 1: 12 fragment reads; 2: + one buffer_load_dwordx4; 3: + two; 4: two loads + a 16-byte LDS store
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4p;
+        const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(gsrc, 0, 0x7fffffff, 0x00020000);
         for (int it = 0; it < iters; ++it) {{
 #pragma unroll
             for (int r = 0; r < 12; ++r) {{ const float4 v = *reinterpret_cast<const float4*>(lds + ((lane * 80 + r * 5120 + it * 16) & 65520)); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }}
+            if (LDSW >= 2) {{ const u32x4p v = __builtin_amdgcn_raw_buffer_load_b128(rsp, (threadIdx.x * 16 + it * 8192 + blockIdx.x * 65536) & 0x1ffff0, 0, 0); s.x += __builtin_bit_cast(float, v[0]); }}
+            if (LDSW >= 3) {{ const u32x4p v = __builtin_amdgcn_raw_buffer_load_b128(rsp, (threadIdx.x * 16 + it * 8192 + blockIdx.x * 65536 + 1048576) & 0x1ffff0, 0, 0); s.y += __builtin_bit_cast(float, v[1]); }}
+            if (LDSW >= 4) *reinterpret_cast<float4*>(lds + 32768 + threadIdx.x * 16) = s;
+            __builtin_amdgcn_s_sleep(6);
         }}
         sink[threadIdx.x] = s.x + s.y + s.z + s.w;
         return;
@@ -137,30 +160,30 @@ template <int LDSW> __global__ __launch_bounds__(512) void k_{p}(unsigned long l
                      : [acc0] "+v"(acc0), [acc1] "+v"(acc1), [acc2] "+v"(acc2), [acc3] "+v"(acc3), [acc4] "+v"(acc4), [acc5] "+v"(acc5), [acc6] "+v"(acc6), [acc7] "+v"(acc7),
                        [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]), [x6] "+v"(x[6]), [x7] "+v"(x[7]),
                        [x8] "+v"(x[8]), [x9] "+v"(x[9]), [x10] "+v"(x[10]), [x11] "+v"(x[11]), [x12] "+v"(x[12]), [x13] "+v"(x[13]), [x14] "+v"(x[14]), [x15] "+v"(x[15]),
-                       [d0] "+v"(d[0]), [d1] "+v"(d[1]), [d2] "+v"(d[2]), [d3] "+v"(d[3])
-                     : [a] "v"(a), [b] "v"(b), [c0] "v"(c0), [c1] "v"(c1));
+                       [d0] "+v"(d[0]), [d1] "+v"(d[1]), [d2] "+v"(d[2]), [d3] "+v"(d[3]), [f0] "+v"(f0), [f1] "+v"(f1), [f2] "+v"(f2), [f3] "+v"(f3)
+                     : [a] "v"(a), [b] "v"(b), [c0] "v"(c0), [c1] "v"(c1), [la] "v"(la), [va] "v"(va), [rs] "s"(rs));
     }}
     t1 = __builtin_readcyclecounter();
     float s = 0.f;
     for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i] + acc2[i] + acc3[i] + acc4[i] + acc5[i] + acc6[i] + acc7[i] + x[i];
-    sink[threadIdx.x] = s + d[0] + d[1] + d[2] + d[3];
+    sink[threadIdx.x] = s + d[0] + d[1] + d[2] + d[3] + f0[0] + f1[0] + f2[0] + f3[0];
     if (lane == 0 && blockIdx.x == 7) out[wave] = t1 - t0;
 }}
 ''')
 out.append('''
 int main() {
     unsigned long long* out; float* sink;
-    hipMalloc(&out, 64); hipMalloc(&sink, 4096);
+    hipMalloc(&out, 64); hipMalloc(&sink, 4096); void* gsrc; hipMalloc(&gsrc, 1 << 26); hipMemset(gsrc, 0, 1 << 26);
     const int iters = 2000;
     unsigned long long h[8];
 #define RUN(NAME, L)                                                                                          \\
     { hipMemset(out, 0, 64);                                                                                  \\
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_##NAME<L>), dim3(256), dim3(512), 0, 0, out, sink, iters); hipDeviceSynchronize(); \\
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_##NAME<L>), dim3(256), dim3(512), 0, 0, out, sink, iters); hipDeviceSynchronize(); \\
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_##NAME<L>), dim3(256), dim3(512), 0, 0, out, sink, iters, gsrc); hipDeviceSynchronize(); \\
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_##NAME<L>), dim3(256), dim3(512), 0, 0, out, sink, iters, gsrc); hipDeviceSynchronize(); \\
       hipMemcpy(h, out, 64, hipMemcpyDeviceToHost);                                                           \\
       printf("%-14s partner-LDS-wave=%d : %7.1f cycles per 16-MFMA phase (waves 0-3: %llu %llu %llu %llu)\\n", #NAME, L, (double)h[0] / iters, h[0], h[1], h[2], h[3]); }
 ''')
 for p in PATTERNS:
-    out.append(f"    RUN({p}, 0) RUN({p}, 1)\n")
+    out.append(f"    RUN({p}, 0) RUN({p}, 1) RUN({p}, 2) RUN({p}, 3) RUN({p}, 4)\n")
 out.append("    return 0;\n}\n")
 open(sys.argv[1] if len(sys.argv) > 1 else "scripts/microbench/mfma_filler.hip", "w").write("".join(out))

@@ -25,6 +25,9 @@ namespace use {
 constexpr int V4_TW = 32, V4_TH = 16;             // tile: 16 rows x 32 columns
 constexpr int V4_HW = V4_TW + 2, V4_HH = V4_TH + 2;
 constexpr int V4_BN = 128;
+#ifndef V4_ABL                      /* timing-only ablation builds (results wrong): bit 1 transform off, 2 no halo loads / piece stores, */
+#define V4_ABL 0                    /* 4 no weight loads / stores, 8 no fragment reads, 16 no epilogue, 32 no chunk-0 staging in the prologue */
+#endif
 #ifdef USE_HIP_XF_LEGACY            /* A/B builds only: the round 1-3 form (transform left to the compiler's scheduling) */
 constexpr bool V4_XF_LEGACY = true;
 #else
@@ -36,15 +39,25 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     typedef Mfma<TIN> MF;
     constexpr int VEC = 16 / sizeof(TIN);
     constexpr int PARTS = CK / VEC;                          // 16-byte pieces per pixel row of a chunk (4)
-    constexpr int ROWB = CK * (int)sizeof(TIN) + 16;         // 80: conflict-free for the 16-lane ds_read_b128 groups
+    constexpr int PXB = CK * (int)sizeof(TIN);               // 64 bytes per pixel row of a chunk (and per weight row of a slab)
     constexpr int BN = V4_BN, TM = 2, TN = 4;
     constexpr int KSTEPS = CK / MF::KM;
-    constexpr int KB = MF::KM * (int)sizeof(TIN);
-    constexpr int HPITCH = V4_HW * ROWB;                     // a 32-pixel fragment never crosses a halo row
-    constexpr int HALO_BYTES = V4_HH * HPITCH, W_BYTES = BN * ROWB;
+    // LDS layout (round 4): UNPADDED 64-byte rows with the 16-byte piece q of row P stored at slot q ^ ((P >> 2) & 3) - the layout the
+    // blob's slab copy already has.  The round 1-3 layout padded rows to 80 bytes: conflict-free for the fragment reads, but every
+    // 16-byte staging store (4 lanes per row, 8 lanes per LDS cycle) then straddled two rows 20 banks apart and hit 4 banks twice;
+    // pricing the piece stores alone (lane-linear dummy addresses) gave 7 % of the kernel, the weight stores have the same pattern.
+    // Here a staging store writes 128 contiguous bytes per 8 lanes (the slot permutation stays inside a row), the weight store is
+    // lane-linear, and the 16-lane groups of a fragment read still see 16 distinct 16-byte bank groups: lanes of equal P mod 4 in
+    // a group are 12, 20, 24 (or 4, 12, 24) rows apart, i.e. their (P >> 2) & 3 differ.  Halo rows are 48 pixels apart (34 used):
+    // a multiple of 16, so that (P >> 2) & 3 of a lane's pixel depends on the tap's column shift only (3 address registers, one per
+    // shift; the row shift and the k step are immediate offsets / one XOR); the 14 spare pixels of a row take the dummy stores.
+    constexpr int HROW = 48;                                 // pixels between halo rows in LDS
+    constexpr int HPITCH = HROW * PXB;                       // 3072
+    constexpr int HALO_BYTES = V4_HH * HPITCH, W_BYTES = BN * PXB;   // 55,296 / 8,192
     constexpr int MAIN_BYTES = 2 * HALO_BYTES + 2 * W_BYTES;
     constexpr int NPIECE = V4_HH * V4_HW * PARTS;            // 2448 pieces per halo chunk
     constexpr int PIECE_ITERS = (NPIECE + 511) / 512;        // 5
+    static_assert(PXB == 64, "v4 LDS layout: 64-byte rows");
     static_assert(PARTS == 4 && PIECE_ITERS == 5 && BN * PARTS == 512, "v4 staging layout");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,15 +90,21 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     // VMEM queue of the very waits it is meant to observe (round 4: that form inflated the LDS phases 2-3x).
     const bool tracing = p.trace != nullptr && (int)(blockIdx.x + gridDim.x * blockIdx.z) == p.dbg && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0;
     int trace_n = 0;
-    unsigned long long* const trace_lds = reinterpret_cast<unsigned long long*>(smem + 147456) + (wave >> 2) * 248;
+    unsigned long long* const trace_lds = reinterpret_cast<unsigned long long*>(smem + 152064) + (wave >> 2) * 248;
 #define V4_STAMP(ID)                                                                                   \
     if (tracing && trace_n < 124) {                                                                    \
         trace_lds[2 * trace_n] = (unsigned long long)(ID);                                             \
         trace_lds[2 * trace_n + 1] = __builtin_readcyclecounter(); ++trace_n;                          \
     }
+#ifdef USE_HIP_TRACE_PHASES   /* per-phase stamps cost ~100 cycles each: off for chunk-level cycle accounting (ids 50 + c) */
 #define V4_TRACE_FORCE(R) asm volatile("" :: "v"((R).x), "v"((R).y), "v"((R).z), "v"((R).w));
 #define V4_PSTAMP_C(C_, ID) if ((C_) >= 1 && (C_) <= 2) { V4_STAMP(ID) }
-#define V4_PSTAMP(ID) if (c >= 1 && c <= 2) { V4_STAMP(ID) }   /* per-phase stamps of the second and third K chunk: 1xx = end of MFMA(T), 2xx = end of LDS(T) (before the barrier) */
+#define V4_PSTAMP(ID) if (c >= 1 && c <= 2) { V4_STAMP(ID) }
+#else
+#define V4_TRACE_FORCE(R)
+#define V4_PSTAMP_C(C_, ID)
+#define V4_PSTAMP(ID)
+#endif   /* per-phase stamps of the second and third K chunk: 1xx = end of MFMA(T), 2xx = end of LDS(T) (before the barrier) */
 #else
 #define V4_STAMP(ID)
 #define V4_PSTAMP(ID)
@@ -94,49 +113,33 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
 #endif
     V4_STAMP(1)
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = addv[j];   // bias + time-embedding bias: the sum starts there
 
-    int a_base[TM], b_base[TN];                              // LDS byte offsets of this lane's fragments
+    V4_STAMP(11)
+    // LDS byte offsets of this lane's fragments.  k index of a lane's first element inside the 64-byte row: (kk, h = lane >> 5) ->
+    // piece q and offset o inside it: 16-bit types q = 2 kk + h, o = 0 (8 elements = one piece per lane); fp32 q = kk >> 1,
+    // o = 4 ((kk & 1) 2 + h).  Address = row * 64 + ((q ^ swz) << 4) + o = (lane-constant base) ^ KX(kk) + KO(kk).
+    constexpr bool W16 = sizeof(TIN) == 2;
+    const int h_ = lane >> 5, col_ = lane & 31;
+#define V4_KX(KK) (W16 ? ((KK) * 2) << 4 : ((KK) >> 1) << 4)
+#define V4_KO(KK) (W16 ? 0 : ((KK)&1) * 8)
+    int a_dx[3];                                             // per column shift dx of the tap: pixel (row 2 wave, column col_ + dx)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-        a_base[i] = (wave * 2 + i) * HPITCH + (lane & 31) * ROWB + (lane >> 5) * MF::KPL * (int)sizeof(TIN);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-        b_base[j] = 2 * HALO_BYTES + (j * 32 + (lane & 31)) * ROWB + (lane >> 5) * MF::KPL * (int)sizeof(TIN);
+    for (int dx = 0; dx < 3; ++dx) {
+        const int P = col_ + dx;                             // (+ row * 48: does not change (P >> 2) & 3)
+        a_dx[dx] = wave * 2 * HPITCH + P * PXB + (((W16 ? h_ : 0) ^ ((P >> 2) & 3)) << 4) + (W16 ? 0 : h_ * 4);
+    }
+    const int b_0 = 2 * HALO_BYTES + col_ * PXB + (((W16 ? h_ : 0) ^ ((col_ >> 2) & 3)) << 4) + (W16 ? 0 : h_ * 4);   // weight row j * 32 + col_: + j * 2048
 
     // ---- segment-0 halo pieces: this thread's piece j (0..4) of every chunk --------------------------------------------
     // Per piece: the pixel offset of its global load and the byte offset of its LDS row - kept in two LDS tables (read back by the
     // owning thread only), not in registers: the register file is what limits the depth of the load pipeline below.  Pieces outside
     // the image (zero padding, applied AFTER the activation) are zeroed ONCE here in both halo buffers and from then on written into
-    // the unused 16-byte tail of their 80-byte LDS row: no per-piece mask in the main loop.
+    // one of the 14 spare pixels of a halo row: no per-piece mask in the main loop.
     constexpr int COEF_OFF = MAIN_BYTES;                     // [Ctot <= 512] float2
     constexpr int TAB_OFF = COEF_OFF + 512 * 8;              // [2][PIECE_ITERS][512] int
     int* const pix_tab = reinterpret_cast<int*>(smem + TAB_OFF);
     int* const dst_tab = pix_tab + PIECE_ITERS * 512;
-#pragma unroll
-    for (int j = 0; j < PIECE_ITERS; ++j) {
-        const int idx = j * 512 + tid;
-        const int pix = idx < NPIECE ? idx / PARTS : idx / PARTS - V4_HH * V4_HW;     // (threads without a fifth piece: a pad slot of row 0)
-        const int hy = pix / V4_HW, hx = pix - hy * V4_HW;
-        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        const bool inb = idx < NPIECE && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        int pp = inb ? gy * p.W + gx : 0;                    // pixel offset inside the item's image (the item offset sits in the buffer base)
-#ifdef USE_HIP_ABLATE
-        if (p.dbg & 1) pp = idx & 127;                       // timing only: every halo load hits the same 32 KB (cache-resident): prices the exposed load latency
-#endif
-        const int row = hy * HPITCH + hx * ROWB;
-        if (idx < NPIECE && !inb) {
-            *reinterpret_cast<uint4*>(smem + row + part * 16) = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(smem + HALO_BYTES + row + part * 16) = make_uint4(0, 0, 0, 0);
-        }
-        pix_tab[idx] = pp;
-        dst_tab[idx] = inb ? row + part * 16 : row + CK * (int)sizeof(TIN);
-    }
+    const int dummy_slot = ((tid / 56) * HROW + V4_HW) * PXB + (tid % 56) * 16;   // rows 0..9, pixels 34..47
     // GroupNorm affine (a, b) of every input channel of this item in LDS: finalised here from the producers' totals (or copied
     // from a coefficient array, or the identity) - no separate finalize launch, and the per-chunk reads are LDS reads
     float2* const coef_lds = reinterpret_cast<float2*>(smem + COEF_OFF);   // filled in the prologue, behind the first loads
@@ -175,13 +178,14 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     };
     auto piece1_dst = [&](int q, int hb) -> int {
         const int pix = (q * 512 + tid) / PARTS;
-        return hb * HALO_BYTES + ((pix >> 5) + 1) * HPITCH + ((pix & 31) + 1) * ROWB + part * 16;
+        const int P = ((pix >> 5) + 1) * HROW + (pix & 31) + 1;
+        return hb * HALO_BYTES + P * PXB + ((part ^ ((P >> 2) & 3)) << 4);
     };
 
     // ---- weights: slab-major copy [tap][chunk][cout_pad][CK]; one 16-byte piece per thread per slab ----------------------
     const unsigned wvoff = (unsigned)tid * 16u;
-    // the slab rows of the blob are piece-swizzled (use_kernels.h, ConvArgs::wb): undo it while writing the padded LDS rows
-    const int wdst = 2 * HALO_BYTES + (tid / PARTS) * ROWB + (part ^ (((tid / PARTS) >> 2) & 3)) * 16;
+    // the slab rows of the blob are piece-swizzled (use_kernels.h, ConvArgs::wb) exactly as the LDS image wants them: lane-linear store
+    const int wdst = 2 * HALO_BYTES + tid * 16;
     const unsigned slab_b = (unsigned)(p.cout_pad * CK) * (unsigned)sizeof(TIN);     // bytes per (tap, chunk) slab
     const unsigned n0_b = (unsigned)(n0 * CK) * (unsigned)sizeof(TIN);
     // weights of iteration (chunk CC, tap TT) -> R ; TT may run past 8 (wraps into the next chunk)
@@ -204,27 +208,84 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     // (L2-resident: every workgroup reads the same 295 KB) is issued in LDS(n-2) BEFORE that phase's halo load, stored in LDS(n-1) -
     // its wait (vmcnt(1)) leaves the younger, slower halo load in flight - and read in LDS(n).  Two full iterations of cover (three
     // halo sets, consumption in MFMA(k+2)) do not fit the 256 registers of a wave: 41 spills.
-    uint4 wS, hL[2];
+    uint4 wS, hL[3];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    wS = hL[0] = hL[1] = zero4;
+    wS = hL[0] = hL[1] = hL[2] = zero4;
     {
+        // Order (round 4, cycle stamps of a steady-state workgroup: 15.1 k cycles from launch to the first MFMA of a 68 k tile, 5.5 k of
+        // them the arrival of these 55 KB at the ~10 B / cycle a CU gets, and 4 k of address arithmetic in FRONT of their issue): the
+        // pixel offsets of the five pieces first and their loads at once, weights and GroupNorm affine behind them, and everything that
+        // needs no memory - LDS slots, tables, zeroing of the padding, accumulator start values - in the shadow of the latency; the
+        // pieces are then transformed one by one as they arrive.
+        V4_STAMP(12)
         uint4 w0 = zero4, raw[PIECE_ITERS];
+        int slot[PIECE_ITERS], ppv[PIECE_ITERS]; bool inbv[PIECE_ITERS];
+#pragma unroll
+        for (int j = 0; j < PIECE_ITERS; ++j) {
+            const int idx = j * 512 + tid;
+            const int pix = idx < NPIECE ? idx / PARTS : 0;
+            const int hy = pix / V4_HW, hx = pix - hy * V4_HW;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const bool inb = idx < NPIECE && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            int pp = inb ? gy * p.W + gx : 0;                // pixel offset inside the item's image (the item offset sits in the buffer base)
+#ifdef USE_HIP_ABLATE_HALO
+            pp = idx & 127;                                  // (compile-time form: p.dbg is the traced workgroup in trace builds)
+#endif
+#ifdef USE_HIP_ABLATE
+            if (p.dbg & 1) pp = idx & 127;                   // timing only: every halo load hits the same 32 KB (cache-resident): prices the exposed load latency
+#endif
+            raw[j] = (V4_ABL & 32) ? zero4 : src_ld0(0, pp);
+            const int P = hy * HROW + hx;
+            slot[j] = P * PXB + ((part ^ ((P >> 2) & 3)) << 4);
+            ppv[j] = pp; inbv[j] = inb;
+            if (idx >= NPIECE) slot[j] = -1;
+        }
         V4_LOAD_W(0, 0, w0);
         V4_LOAD_W(0, 1, wS);                                 // stored by LDS(0)
+        float2 cfv = make_float2(1.f, 0.f);                  // GroupNorm affine of input channel tid of this item
+        if (tid < Ctot)
+            cfv = p.gn_st0 ? gn_coef_of(p.gn_st0, p.C0, p.gn_st1, p.C1, p.gn_gamma, p.gn_beta, p.gn_groups, p.gn_inv_n, p.gn_eps, b, tid)
+                  : p.coef ? *reinterpret_cast<const float2*>(p.coef + ((size_t)b * Ctot + tid) * 2) : make_float2(1.f, 0.f);
+        __builtin_amdgcn_sched_barrier(0);                   // the loads above are issued before anything below
+        V4_STAMP(13)
 #pragma unroll
-        for (int j = 0; j < PIECE_ITERS; ++j) raw[j] = src_ld0(0, pix_tab[j * 512 + tid]);
-        gn_fill_table(coef_lds, p, b, Ctot, tid, 512);       // while the halo / weight loads are in flight
+        for (int j = 0; j < PIECE_ITERS; ++j) {
+            const int idx = j * 512 + tid;
+            if (slot[j] >= 0 && !inbv[j]) {
+                *reinterpret_cast<uint4*>(smem + slot[j]) = zero4;
+                *reinterpret_cast<uint4*>(smem + HALO_BYTES + slot[j]) = zero4;
+            }
+            pix_tab[idx] = ppv[j];
+            slot[j] = inbv[j] ? slot[j] : dummy_slot;
+            dst_tab[idx] = slot[j];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = addv[j];   // bias + time-embedding bias: the sum starts there
+        if (tid < Ctot) coef_lds[tid] = cfv;
+        V4_STAMP(14)
         __syncthreads();                                     // coef_lds complete
+        V4_STAMP(15)
         load_coef(0);
         V4_STORE_W(0, w0);
+        V4_STAMP(16)
 #pragma unroll
         for (int j = 0; j < PIECE_ITERS; ++j)
-            *reinterpret_cast<uint4*>(smem + dst_tab[j * 512 + tid]) = stage_transform<TIN, ACT>(raw[j], 0xffffffffu, ca, cb);
+            *reinterpret_cast<uint4*>(smem + slot[j]) = (V4_ABL & 32) ? raw[j] : stage_transform<TIN, ACT>(raw[j], 0xffffffffu, ca, cb);
     }
 
     typename MF::frag af[KSTEPS][TM], bf[KSTEPS][TN];
     int dst_ = 0;                                            // LDS address of the piece the next MFMA phase transforms
-#define V4_XF_PHASE(T) ((T) >= 1 && (T) < PIECE_ITERS + 1)   /* MFMA(T) carries the transform of piece T - 1 */
+    uint4 tkeep = zero4; int dkeep = 0;                      // (ablation 512 only)
+#ifdef USE_HIP_SETPRIO
+#define V4_SETPRIO(N) __builtin_amdgcn_s_setprio(N);
+#else
+#define V4_SETPRIO(N)
+#endif
+#define V4_XF_PHASE(T) ((T) >= 2 && (T) < PIECE_ITERS + 2)   /* MFMA(T) carries the transform of piece T - 2 */
 #define V4_LDS(CC, T)                                                                                                \
     {                                                                                                                \
         const int cc_ = (CC);                                                                                        \
@@ -232,37 +293,54 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         const int cn_ = cc_ + 1 < nchunks ? cc_ + 1 : cc_;   /* chunk being staged (last chunk: itself again, results unused - */ \
         int pix_ = 0;                                        /* everything below is unconditional, see V4_LOAD_W)             */ \
         /* table entries first: they return ahead of the fragments */                                                \
-        if ((T) < PIECE_ITERS) pix_ = pix_tab[((T) < PIECE_ITERS ? (T) : 0) * 512 + tid];                            \
-        if (V4_XF_PHASE(T)) dst_ = dst_tab[(V4_XF_PHASE(T) ? (T)-1 : 0) * 512 + tid];                                \
+        if ((T) < PIECE_ITERS) pix_ = (V4_ABL & 128) ? tid * 3 : pix_tab[((T) < PIECE_ITERS ? (T) : 0) * 512 + tid]; \
+        if (V4_XF_PHASE(T)) dst_ = (V4_ABL & 128) ? tid * 80 : dst_tab[(V4_XF_PHASE(T) ? (T)-2 : 0) * 512 + tid];    \
         {                                                                                                            \
-            const char* ha_ = smem + par_ * HALO_BYTES + ((T) / 3) * HPITCH + ((T) % 3) * ROWB;                      \
+            const char* ha_ = smem + par_ * HALO_BYTES + ((T) / 3) * HPITCH;                                         \
             const char* wbuf_ = smem + (par_ ^ ((T)&1)) * W_BYTES;                                                   \
+            if (!(V4_ABL & 8) || ((CC) == 0 && (T) == 0))                                                            \
             _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk) {                                                  \
-                _Pragma("unroll") for (int i = 0; i < TM; ++i) af[kk][i] = MF::ld(ha_ + a_base[i] + kk * KB);        \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[kk][j] = MF::ld(wbuf_ + b_base[j] + kk * KB);      \
+                int ak_ = a_dx[(T) % 3], bk_ = b_0;                                                                  \
+                if (!W16) asm volatile("" : "+v"(ak_), "+v"(bk_));   /* fp32: 4 XOR variants x 4 bases hoisted out of the loop spill */ \
+                ak_ ^= V4_KX(kk); bk_ ^= V4_KX(kk);                                                                  \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) af[kk][i] = MF::ld(ha_ + ak_ + i * HPITCH + V4_KO(kk)); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[kk][j] = MF::ld(wbuf_ + bk_ + j * 32 * PXB + V4_KO(kk)); \
             }                                                                                                        \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if ((V4_ABL & 512) && (T) >= 3 && (T) < PIECE_ITERS + 3) *reinterpret_cast<uint4*>(smem + dkeep) = tkeep;    \
         if (V4_XF_PHASE(T)) dst_ += (par_ ^ 1) * HALO_BYTES; /* where MFMA(T) puts its transformed piece */          \
+        if ((V4_ABL & 256) && V4_XF_PHASE(T)) dst_ = (par_ ^ 1) * HALO_BYTES + tid * 16;                             \
+        if (!(V4_ABL & 4)) {                                                                                         \
         V4_STORE_W((par_ ^ ((T)&1)) ^ 1, wS);                                                                        \
         V4_LOAD_W(cc_, (T) + 2, wS);                                                                                 \
+        }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                   /* the slab load stays older than the halo load */      \
         if ((T) < PIECE_ITERS) {                                                                                     \
             if ((T) == 0) load_coef(cn_);                                                                            \
-            hL[(T)&1] = src_ld0(cn_, pix_);                                                                          \
+            hL[(T) % 3] = src_ld0(cn_, pix_);                                                                          \
         }                                                                                                            \
     }
 #define V4_MFMA(CC, T)                                                                                               \
     {                                                                                                                \
+        V4_SETPRIO(1)                                                                                                \
         if constexpr (sizeof(TIN) == 2 && !V4_XF_LEGACY) {                                                           \
             if (V4_XF_PHASE(T)) {                            /* unconditional at run time: same basic block as the MFMAs */ \
                 /* 16 MFMAs, slice g of the GroupNorm + SiLU transform of one halo piece behind MFMA g, one asm statement */ \
                 /* each (use_device.h, XfAsm: left to itself hipcc runs the transform with the matrix pipe idle)          */ \
                 V4_PSTAMP_C(CC, 300 + (T))                        /* trace builds: 3xx -> 4xx = the exposed wait for the halo piece */ \
-                V4_TRACE_FORCE(hL[(V4_XF_PHASE(T) ? (T)-1 : 0) & 1])                                                 \
+                V4_TRACE_FORCE(hL[(V4_XF_PHASE(T) ? (T)-2 : 0) % 3])                                                 \
                 V4_PSTAMP_C(CC, 400 + (T))                                                                               \
-                const uint4 t0 = mfma16_with_transform<TIN, ACT>(acc, af, bf, hL[(V4_XF_PHASE(T) ? (T)-1 : 0) & 1], ca, cb); \
-                *reinterpret_cast<uint4*>(smem + dst_) = t0; /* the other halo buffer: nobody reads it during this chunk */ \
+                if (V4_ABL & 1) {                                                                                    \
+                    _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk)                                            \
+                        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                               \
+                            _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);  \
+                    if (!(V4_ABL & 64)) *reinterpret_cast<uint4*>(smem + dst_) = hL[(V4_XF_PHASE(T) ? (T)-2 : 0) % 3];  \
+                } else {                                                                                             \
+                const uint4 t0 = mfma16_with_transform<TIN, ACT>(acc, af, bf, hL[(V4_XF_PHASE(T) ? (T)-2 : 0) % 3], ca, cb); \
+                if (V4_ABL & 512) { tkeep = t0; asm volatile("" : "+v"(tkeep.x), "+v"(tkeep.y), "+v"(tkeep.z), "+v"(tkeep.w)); dkeep = dst_; } \
+                else if (!(V4_ABL & 64)) *reinterpret_cast<uint4*>(smem + dst_) = t0; /* the other halo buffer: nobody reads it during this chunk */ \
+                }                                                                                                    \
             } else {                                                                                                 \
                 _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk)                                                \
                     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
@@ -273,7 +351,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
                 _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                       \
                     _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);  \
             if (V4_XF_PHASE(T)) {                                                                                    \
-                const uint4 t0 = stage_transform<TIN, ACT>(hL[(V4_XF_PHASE(T) ? (T)-1 : 0) & 1], 0xffffffffu, ca, cb); \
+                const uint4 t0 = stage_transform<TIN, ACT>(hL[(V4_XF_PHASE(T) ? (T)-2 : 0) % 3], 0xffffffffu, ca, cb); \
                 *reinterpret_cast<uint4*>(smem + dst_) = t0;                                                         \
                 _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                     \
                     __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * KSTEPS / 16, 0);   /* MFMA  */             \
@@ -282,6 +360,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
                 }                                                                                                    \
             }                                                                                                        \
         }                                                                                                            \
+        V4_SETPRIO(0)                                                                                                \
     }
 
     // Ping-pong over the 3x3 segment: the two waves that share a SIMD (w and w+4) are always in opposite phases.
@@ -299,6 +378,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         V4_LDS(0, 0)
         V4_BAR();
         for (int c = 0; c < nchunks; ++c) {
+            V4_STAMP(50 + c)
 #define V4_G0_STEP(T) V4_MFMA(c, T) V4_PSTAMP(100 + (T)) V4_BAR_M(); V4_LDS(c, (T) + 1) V4_PSTAMP(200 + (T) + 1) V4_BAR();
             V4_G0_STEP(0) V4_G0_STEP(1) V4_G0_STEP(2) V4_G0_STEP(3) V4_G0_STEP(4) V4_G0_STEP(5) V4_G0_STEP(6) V4_G0_STEP(7)
 #undef V4_G0_STEP
@@ -310,6 +390,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     } else {
         V4_BAR();
         for (int c = 0; c < nchunks; ++c) {
+            V4_STAMP(50 + c)
 #define V4_G1_STEP(T) V4_LDS(c, T) V4_PSTAMP(200 + (T)) V4_BAR(); V4_MFMA(c, T) V4_PSTAMP(100 + (T)) V4_BAR_M();
             V4_G1_STEP(0) V4_G1_STEP(1) V4_G1_STEP(2) V4_G1_STEP(3) V4_G1_STEP(4) V4_G1_STEP(5) V4_G1_STEP(6) V4_G1_STEP(7) V4_G1_STEP(8)
 #undef V4_G1_STEP
@@ -321,6 +402,17 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
 #undef V4_LOAD_W
 
     V4_STAMP(4)
+    if (V4_ABL & 16) {                                       // timing only: no epilogue (one value per lane keeps the accumulators alive)
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+        if (sum == 1.2345f) ((float*)p.out)[tid] = sum;
+        return;
+    }
     // ---- segment 1: the fused 1x1 shortcut: raw centre pixels; double-buffered, one barrier per iteration ---------------
     if (nchunks2 > 0) {
         uint4 r0, r1, r2, r3, wa; unsigned m0, m1, m2, m3;
@@ -340,14 +432,14 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
             V4_STORE_W(buf, wa);
             __syncthreads();
             if (c2 + 1 < nchunks2) V4_SC_LOAD(c2 + 1)
-            const char* ha_ = smem + buf * HALO_BYTES + HPITCH + ROWB;        // centre tap
+            const char* ha_ = smem + buf * HALO_BYTES + HPITCH;               // centre tap: row shift 1, column shift 1 (a_dx[1])
             const char* wb2_ = smem + buf * W_BYTES;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[kk][i] = MF::ld(ha_ + a_base[i] + kk * KB);
+                for (int i = 0; i < TM; ++i) af[kk][i] = MF::ld(ha_ + (a_dx[1] ^ V4_KX(kk)) + i * HPITCH + V4_KO(kk));
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[kk][j] = MF::ld(wb2_ + b_base[j] + kk * KB);
+                for (int j = 0; j < TN; ++j) bf[kk][j] = MF::ld(wb2_ + (b_0 ^ V4_KX(kk)) + j * 32 * PXB + V4_KO(kk));
             }
             V4_MFMA(nchunks, 0)
         }
@@ -356,14 +448,11 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     V4_STAMP(5)
     __syncthreads();                                         // the epilogue re-uses the LDS
     V4_STAMP(6)
-#ifdef USE_HIP_TRACE_BUILD
-    if (tracing) {                                           // (the epilogue's own stamps 7 / 8 are not recorded in this form)
-        for (int i = 0; i < 2 * trace_n; ++i) p.trace[(wave >> 2) * 256 + i] = trace_lds[i];
-    }
-#endif
 #undef V4_MFMA
 #undef V4_XF_PHASE
 #undef V4_STORE_W
+#undef V4_KX
+#undef V4_KO
 
     // ------------------------------ epilogue: per-wave LDS transpose, 16-byte I/O ------------------------------------------
     // VALU diet (the epilogue used to be 47 % of the kernel's VALU instructions, all of them outside the MFMAs' shadow):
@@ -485,19 +574,23 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         }
     }
     V4_STAMP(8)
+#ifdef USE_HIP_TRACE_BUILD
+    if (tracing) {
+        for (int i = 0; i < 2 * trace_n; ++i) p.trace[(wave >> 2) * 256 + i] = trace_lds[i];
+    }
+#endif
 }
 
 template <typename TIN, typename TOUT, int CK, bool ACT>
 static void v4_launch_t(const ConvArgs& a, hipStream_t s) {
-    constexpr int ROWB = CK * (int)sizeof(TIN) + 16;
-    constexpr int MAIN = 2 * V4_HH * V4_HW * ROWB + 2 * V4_BN * ROWB + 512 * 8 + 2 * 5 * 512 * 4;   // halo + weight buffers, GroupNorm table, piece tables
+    constexpr int MAIN = 2 * V4_HH * 48 * 64 + 2 * V4_BN * 64 + 512 * 8 + 2 * 5 * 512 * 4;   // halo + weight buffers, GroupNorm table, piece tables
     constexpr int EPI = 8 * 32 * (V4_BN + 4) * 4 + 8 * V4_BN * 2 * 4;
 #ifdef USE_HIP_TRACE_BUILD
-    constexpr int SMEM = 147456 + 2 * 248 * 8;               // + the stamp buffers
+    constexpr int SMEM = 152064 + 2 * 248 * 8;               // + the stamp buffers
 #else
     constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
 #endif
-    static_assert(MAIN <= 147456 && EPI <= 147456 && SMEM <= 163840, "LDS budget");
+    static_assert(MAIN <= 152064 && EPI <= 152064 && SMEM <= 163840, "LDS budget");
     static bool attr_set = false;
     auto kern = conv_v4_kernel<TIN, TOUT, CK, ACT>;
     if (!attr_set) {
