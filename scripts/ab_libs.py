@@ -18,6 +18,9 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("gcb", os.path.join(os.environ["USE_ROOT"], "scripts", "gpu_conv_bench.py"))
 g = importlib.util.module_from_spec(spec); spec.loader.exec_module(g)
 names = json.loads(os.environ["AB_CASES"]); variant = int(os.environ["AB_VARIANT"]); iters = int(os.environ["AB_ITERS"])
+from universal_speech_enhancement_amd import _lib
+for kv in filter(None, os.environ.get("AB_OPTS", "").split(";")):
+    _lib.check(_lib.lib().use_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1])), "use_set_option")
 res = {}
 for n in names:
     best = None
@@ -52,7 +55,8 @@ def main():
     results = {}
     for rnd in range(a.rounds):
         for lib in a.libs:
-            env = dict(os.environ, USE_ROOT=ROOT, USE_HIP_LIB=os.path.join(ROOT, lib), AB_CASES=json.dumps(names), AB_VARIANT=str(a.variant), AB_ITERS=str(a.iters))
+            path, _, opts = lib.partition("@")            # lib.so@option=value;option=value
+            env = dict(os.environ, USE_ROOT=ROOT, USE_HIP_LIB=os.path.join(ROOT, path), AB_CASES=json.dumps(names), AB_VARIANT=str(a.variant), AB_ITERS=str(a.iters), AB_OPTS=opts)
             r = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True, timeout=1200)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("AB_RESULT ")]
             if not line:
@@ -66,14 +70,16 @@ def main():
             if not runs:
                 row += f" | {os.path.basename(lib)}: n/a"; continue
             ms = min(r["ms"] for r in runs)
-            row += f" | {os.path.basename(lib)[10:-3] or 'head'}: {ms:7.3f} ms {runs[0]['flops'] / ms / 1e9:7.1f} TF"
+            tag = (os.path.basename(lib.partition("@")[0])[10:-3] or "head") + ("@" + lib.partition("@")[2] if "@" in lib else "")
+            row += f" | {tag}: {ms:7.3f} ms {runs[0]['flops'] / ms / 1e9:7.1f} TF"
             crcs.add((runs[0]["crc"], runs[0]["stats_crc"], runs[0]["finite"]))
         row += "  outputs " + ("IDENTICAL" if len(crcs) == 1 else f"DIFFER {crcs}")
         print(row, flush=True)
     if a.e2e:
         for rnd in range(2):
             for lib in a.libs:
-                env = dict(os.environ, USE_HIP_LIB=os.path.join(ROOT, lib))
+                path, _, opts = lib.partition("@")
+                env = dict(os.environ, USE_HIP_LIB=os.path.join(ROOT, path), USE_OPTS=opts.replace(";", ","))
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_time_forward.py"), "bf16", "8", "640", "10"], env=env, capture_output=True, text=True, timeout=1200)
                 print(f"e2e {os.path.basename(lib):28s} {r.stdout.strip().splitlines()[-1][:110] if r.stdout.strip() else r.stderr[-500:]}", flush=True)
 

@@ -83,7 +83,7 @@ def test_score_golden_with_wide_tile_kernel_forced(golden_dir, engines, prec, to
     try:
         out = engines[prec].score(x[:, 0:1].contiguous(), x[:, 1:2].contiguous(), torch.from_numpy(g["t_a"]).cuda())
     finally:
-        set_option("conv_v4_min_blocks", 128)
+        set_option("conv_v4_min_blocks", 80)
     err = _relmax(out, -torch.from_numpy(g["out_a"]))
     _check(err, tol, "score vs forward_large, conv_v4 forced", prec)
     with pytest.raises(Exception):
