@@ -70,9 +70,22 @@ def cpu_baseline(sd_np):
         _, _, Y, nfe = so.score_model_sample(lambda xx, t: no.ncsnpp_forward(sd, xx, t), wav, N=N, corrector="langevin",
                                              corrector_steps=1, snr=0.5, noise=so.NoiseSource(replay=draws))
         dt = time.time() - t0
+        # second leg: the configs[1] SHAPE - 4 s utterances, T' = 640 - at N = 2 (4 NFE); one utterance of the
+        # batch of 8 (the batch would take minutes; the CPU path is linear in the batch), scaled linearly in NFE like the first leg
+        L2, N2 = 96000, 2
+        wav2 = torch.from_numpy(tn.synth_noisy_speech(1, L2, seed=1234))
+        draws2 = [torch.from_numpy(d) for d in tn.sampler_noise(4321, 1 + 2 * N2, (1, 1, 512, 640))]
+        t0 = time.time()
+        _, _, _, nfe2 = so.score_model_sample(lambda xx, t: no.ncsnpp_forward(sd, xx, t), wav2, N=N2, corrector="langevin",
+                                              corrector_steps=1, snr=0.5, noise=so.NoiseSource(replay=draws2))
+        dt2 = time.time() - t0
     frames = n_utt * (1 + L // 160)
     frame_nfe_per_s = frames * nfe / dt
-    return {"value": round(frame_nfe_per_s / 60.0, 4), "unit": "spectrogram-frames/s", "cores": best, "kind": "port",
+    frames2 = 1 + L2 // 160
+    cfg2 = {"value": round(frames2 * nfe2 / dt2 / 60.0, 4), "unit": "spectrogram-frames/s",
+            "sample": f"configs[1] shape: 1 of the 8 utterances x 4 s ({frames2} frames, T'=640), 2-step PC sampler = {nfe2} NFE in {dt2:.1f} s "
+                      f"({frames2 * nfe2 / dt2:.1f} frame*NFE/s), scaled linearly in NFE to 60"}
+    return {"value": round(frame_nfe_per_s / 60.0, 4), "unit": "spectrogram-frames/s", "cores": best, "kind": "port", "cfg2_shape": cfg2,
             "sample": f"CPU oracle (torch fp32, {best} of {avail} usable cores) on BASELINE configs[0] exactly: 1 utterance x 2 s "
                       f"({frames} frames, T'=320), 5-step PC sampler (reverse_diffusion + langevin x1) = {nfe} NFE in {dt:.1f} s "
                       f"({frame_nfe_per_s:.1f} frame*NFE/s; {frames / dt:.2f} frames/s at this 10-NFE sampler), scaled linearly in "
@@ -97,12 +110,14 @@ def main():
                     help="BASELINE.json configs[] preset: 1 = 8 x 4 s, N=30 PC, bf16 (the default, the headline metric); 3 = batch 16, "
                          "N=200, corrector snr 0.5 (long-horizon latency config); 4 = 8 x 4 s per GPU, N=30 PC, fp16 storage (the "
                          "per-GPU workload of the 32-utterance / 4-GPU config)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary sampler configurations (predictor-only, N=50, fp32)")
+    ap.add_argument("--opt", action="append", default=[], help="use_set_option name=value (repeatable; same-box A/B of a tuning knob)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the timed sampler steps; run only the per-launch measurement of the dominant kernel (for "
                          "`rocprofv3 --kernel-trace --stats -- python bench.py --roofline-only`, see profiles/README.md)")
     a = ap.parse_args()
     if a.roofline_only:
-        a.steps, a.warmup, a.no_cpu_baseline = 0, 0, True
+        a.steps, a.warmup, a.no_cpu_baseline, a.no_secondary = 0, 0, True, True
     if a.config == 3:
         a.batch, a.N = 16, 200
     elif a.config == 4:
@@ -119,6 +134,8 @@ def main():
         set_option("subbatch", a.subbatch)
     if a.stagger_level is not None:
         set_option("stagger_level", a.stagger_level)
+    for kv in a.opt:
+        set_option(kv.split("=")[0], int(kv.split("=")[1]))
     rank, world, local = D.init_from_env()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
@@ -176,8 +193,19 @@ def main():
     # (every operand once) / duration between HIP events / 8 TB/s, per kernel class and map, averaged over the launches
     hbm_kernels = []
     groups = {}
-    for name, Hm, Wm, by, ms in eng.profile_aux():
-        groups.setdefault((name, Hm, Wm), []).append((by, ms))
+    mfma_groups = {}
+    for name, Hm, Wm, by, ms, fl in eng.profile_aux(with_flops=True):
+        if fl > 0:
+            mfma_groups.setdefault((name, Hm, Wm), []).append((fl, ms))
+        else:
+            groups.setdefault((name, Hm, Wm), []).append((by, ms))
+    # the MFMA-bound kernels beside the dominant one, per kernel class and map: algorithmic FLOPs / HIP-event duration / dense peak
+    mfma_kernels = []
+    for (name, Hm, Wm), v in sorted(mfma_groups.items(), key=lambda kv: -sum(m for _, m in kv[1])):
+        fl = sum(f for f, _ in v); ms = sum(m for _, m in v)
+        mfma_kernels.append({"kernel": name, "map": f"{Hm}x{Wm}", "launches_per_score": len(v), "algorithmic_gflop_per_launch": round(fl / len(v) / 1e9, 2),
+                             "avg_launch_ms": round(ms / len(v), 4), "ms_per_score": round(ms, 3),
+                             "achieved_TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1)})
     for (name, Hm, Wm), v in sorted(groups.items(), key=lambda kv: (-kv[0][1] * kv[0][2], kv[0][0])):
         if Hm * Wm < 256 * 320:                                     # the smaller maps are hidden behind the other sub-batch's convolutions
             continue
@@ -197,7 +225,7 @@ def main():
     if a.precision == "bf16" and (B, Tp) == (8, 640):   # the PMC passes were collected on exactly this workload
         import glob
         import hashlib
-        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_conv_v4.json")))
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv_v4.json")), key=lambda f: (int(os.path.basename(f).split("_")[0][1:] or 0), f))
         if pm:
             rec = json.load(open(pm[-1]))
             src = os.path.join(ROOT, rec.get("kernel_source", "universal_speech_enhancement_amd/csrc/use_conv_v4.hip"))
@@ -220,7 +248,37 @@ def main():
                 "algorithmic_gflop_per_launch": round(conv_flops / max(conv_launches, 1) / 1e9, 2),
                 "kernel_time_share_of_eager_score": round(conv_ms / total_ms, 3),   # of one un-pipelined evaluation (sub-batches back to back)
                 "whole_path_tflops_per_gpu": round(tflops_path, 1), "whole_path_frac": round(tflops_path / peak, 4),
-                "hbm_peak_TBps": PEAK_HBM_TBPS, "hbm_kernels": hbm_kernels}
+                "hbm_peak_TBps": PEAK_HBM_TBPS, "hbm_kernels": hbm_kernels,
+                "kernels": [dict(k, frac=round(k["achieved_TFLOPs"] / peak, 4)) for k in mfma_kernels[:6]]}
+
+    # ---- secondary numbers of SURVEY.md section 8d (outside the timed region above; each its own graph capture + timed steps):
+    # the predictor-only sampler at the benchmark's N, the reference's STOCK default (model_wrapper.py:39-40, 262-269: N = 50, corrector
+    # "none"), and the fp32 parity mode (the mode the north_star tolerance is stated for) on the same workload
+    secondary = None
+    if rank == 0 and world == 1 and not a.no_secondary and a.steps:
+        def timed(engine, N, corr, steps):
+            engine.plan(B, Tp)
+            engine.set_sampler(N, "reverse_diffusion", corr, 1, 0.5, 3e-2, use_graph=not a.no_graph)
+            engine.sample(Y, seed=1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                o = engine.sample(Y, seed=2 + k)
+            torch.cuda.synchronize()
+            d = (time.perf_counter() - t0) / steps
+            n = N * (1 if corr == "none" else 2)
+            assert torch.isfinite(torch.view_as_real(o)).all()
+            return {"N": N, "corrector": corr, "nfe": n, "frames_per_s": round(B * T / d, 1), "ms_per_step": round(d * 1e3, 2),
+                    "ms_per_nfe": round(d * 1e3 / n, 3), "steps_timed": steps}
+        secondary = {"predictor_only": dict(timed(eng, a.N, "none", 3), note=f"reverse_diffusion alone at the benchmark's N, {a.precision}"),
+                     "reference_stock_default": dict(timed(eng, 50, "none", 2), note=f"ScoreModel.sample defaults (N=50, corrector none), {a.precision}")}
+        if a.precision != "fp32":
+            eng32 = HipScoreEngine(precision="fp32", device=local)
+            eng32.load_state_dict(sd_np)
+            secondary["fp32_parity_mode"] = dict(timed(eng32, a.N, a.corrector, 1), note="fp32 storage, exact-fp32 MFMA: the mode the parity tolerances are stated for")
+            eng32.close()
+        eng.plan(B, Tp)
+        eng.set_sampler(a.N, "reverse_diffusion", a.corrector, 1, 0.5, 3e-2, use_graph=not a.no_graph)
 
     cfg_name = ("configs[1]" if (B, a.N, ncorr, a.precision, a.seconds) == (8, 30, 1, "bf16", 4.0) else
                 "configs[3]" if (B, a.N, ncorr, a.precision, a.seconds) == (16, 200, 1, "bf16", 4.0) else
@@ -240,6 +298,8 @@ def main():
             "padded_frame_nfe_per_s": round(padded_frame_nfe_per_s, 1),
             "roofline": roofline,
         }
+        if secondary is not None:
+            res["secondary"] = secondary
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd_np)
         print(json.dumps(res), flush=True)

@@ -166,6 +166,9 @@ int use_profile_score(use_handle* h, const void* x, const void* y, const float* 
  * (H x W per item of the sub-batch), its algorithmic HBM bytes (every operand once) and its duration between HIP events.  Returns 0,
  * 1 when `index` is past the last record of the most recent use_profile_score, negative on error. */
 int use_profile_aux(use_handle* h, int index, char* name, int name_cap, int* H, int* W, double* bytes, double* ms);
+/* ... the same list also carries the MFMA-bound kernels beside the dominant one ("conv_v2": 3x3 convolutions of the middle maps,
+ * "conv_sk": the smallest maps): their algorithmic FLOPs (0 for the HBM-bound classes). */
+int use_profile_aux_flops(use_handle* h, int index, double* flops);
 /* Single-convolution harness for kernel bring-up and same-box A/B timing (no reference counterpart): builds one fused
  * implicit-GEMM 3x3 convolution (optional second channel-concat source C1, GroupNorm affine + SiLU on the input, bias +
  * time-embedding bias, fused 1x1 shortcut over XC0+XC1 channels, residual, GroupNorm partial sums) on deterministic
@@ -185,7 +188,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
  *   res-block (ResnetBlockBigGANpp, layerspp.py:282-314); channel counts are multiples of 32 (zero-pad smaller ones); `w` is the
  *   reference's [Cout][Cin][3][3] (ntaps 9) or [Cout][Cin] (ntaps 1) tensor, `w2` [Cout][XC]; coef = GroupNorm folded to (a, b) per
  *   (item, channel) or null; stats (zeroed by the caller) receives the fixed-point GroupNorm totals of the output.  variant: 0 = the
- *   library's dispatcher, 1 generic, 2 conv_v2, 4 conv_v4, 7 conv_sk, 8 conv_v7.  Synchronises the stream.
+ *   library's dispatcher, 1 generic, 2 conv_v2, 4 conv_v4, 7 conv_sk.  Synchronises the stream.
  * use_op_fir: upsample_2d / downsample_2d with the [1,3,3,1] kernel (up_or_down_sampling.py:202-264); out_act = FIR(act(a x + b)),
  *   out_raw = FIR(x) (either may be null).
  * use_op_attention: softmax(q k^T / sqrt(C)) v per item (AttnBlockpp core, layerspp.py:84-88), q/k/v/out [B][N][C].

@@ -84,6 +84,7 @@ SYMBOLS = {
     "use_flops_per_score": (C.c_double, [_vp]),
     "use_get_stat": (_i, [_vp, C.c_char_p, C.POINTER(C.c_longlong)]),
     "use_profile_aux": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "use_profile_aux_flops": (_i, [_vp, _i, C.POINTER(C.c_double)]),
     "use_profile_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double)]),
     "use_timesteps": (_i, [_i, _f, C.POINTER(_f)]),
     "use_conv_bench": (_i, [C.POINTER(UseConvCase), _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -163,7 +163,7 @@ struct use_handle {
     // per-launch HIP-event profiling of the dominant conv kernel (use_profile_score)
     bool profile = false, profile_all = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events; std::vector<double> prof_flops, prof_bytes; std::vector<char> prof_main;
     // ... and of the HBM-bound kernels around it (FIR resampling, pyramid heads, input convolution): name, map, algorithmic bytes
-    struct AuxProf { std::string name; int H, W; double bytes; hipEvent_t e0, e1; double ms; };
+    struct AuxProf { std::string name; int H, W; double bytes; hipEvent_t e0, e1; double ms; double flops = 0.0; };
     std::vector<AuxProf> prof_aux;
     std::vector<std::string> prof_desc;
     // introspection
@@ -487,7 +487,6 @@ struct Fwd {
         h->flops += fl;
         // large maps: separate finalize launch into a coefficient array (allocated in the dry run as well: the arena is sized by it)
         const float* coef_arr = (gn && (long)a.H * a.W > g_gn_inline) ? gn_coef(a, a2, *gn) : nullptr;
-        if (res) conv_v7_prepare(w.cout, a.dtype);            // identity slabs of the residual-as-shortcut form (built once, outside any capture)
         if (h->dry) return o;
         ConvArgs p{};
         p.src0 = a.p; p.C0 = a.C; p.src1 = a2 ? a2->p : nullptr; p.C1 = a2 ? a2->C : 0; p.in_dtype = a.dtype;
@@ -507,7 +506,7 @@ struct Fwd {
         p.pyr = pyr; p.w4 = cb ? W<float>(cb->w_off) : nullptr; p.b4 = cb ? W<float>(cb->b_off) : nullptr;
         p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
         p.B = B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
-        const bool main_variant = conv_v4_eligible(p) || conv_v7_eligible(p);        // the dominant kernel (conv_v4_kernel / conv_v7_kernel, large maps)
+        const bool main_variant = conv_v4_eligible(p);        // the dominant kernel (conv_v4_kernel, large maps)
         if (h->profile && (main_variant || (h->profile_all && conv_v2_eligible(p)))) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, s);
@@ -524,6 +523,13 @@ struct Fwd {
             }
             char d[160]; snprintf(d, sizeof d, "%-28s H=%3d W=%3d Cin=%3d Cout=%3d taps=%d gn=%d res=%d sc=%d", w.wname.c_str(), a.H, a.W, w.cin, w.cout, w.ntaps, gn != nullptr, res != nullptr, w2 ? w2->cin : 0);
             h->prof_desc.push_back(d);
+        } else if (h->profile && w.ntaps == 9 && w.cout > 8 && !(a.dtype == DT_F32 && w.cin <= 8)) {
+            // the other implicit-GEMM kernels (conv_v2 on the middle maps, conv_sk on the smallest): MFMA-bound records of the aux list
+            const double es = (double)dtype_size(a.dtype), px = (double)B * a.H * a.W;
+            double by = px * (w.cin + (w2 ? w2->cin : 0)) * es + px * w.cout * dtype_size(out_dtype) * (res ? 2.0 : 1.0);
+            by += (double)w.ntaps * w.cin * w.cout * es + (w2 ? (double)w2->cin * w2->cout * es : 0.0);
+            timed_aux(conv_sk_eligible(p) ? "conv_sk" : conv_v2_eligible(p) ? "conv_v2" : "conv_generic", a.H, a.W, by, [&] { launch_conv(p, s); });
+            h->prof_aux.back().flops = fl;
         } else if (h->profile && (w.cout <= 8 || (a.dtype == DT_F32 && w.cin <= 8))) {
             const double px = (double)B * a.H * a.W;
             const double by = px * w.cin * dtype_size(a.dtype) + px * w.cout * dtype_size(out_dtype) * (res ? 2.0 : 1.0) + (double)w.ntaps * w.cin * w.cout * dtype_size(a.dtype);
@@ -912,19 +918,10 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
     if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
-    if (!strcmp(name, "conv_v7_min_units")) { conv_v7_set_min_units((long)value); return USE_OK; }   // 0: conv_v7 off
-    if (!strcmp(name, "conv_v7_units_per_wg")) { conv_v7_set_units_per_wg((int)value); return USE_OK; }
-    if (!strcmp(name, "conv_v7_max_units")) { conv_v7_set_max_units((long)value); return USE_OK; }
-    if (!strcmp(name, "conv_v7_modes")) { conv_v7_set_modes((int)value); return USE_OK; }           // bit 0: plain, 1: residual, 2: fused shortcut
     if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_mfma16")) { wgrad_set_mfma16((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_blocks")) { wgrad_set_blocks((int)value); return USE_OK; }
     if (!strcmp(name, "conv_sk_max_px")) { conv_sk_set_max_px((long)value); return USE_OK; }             // 0: conv_sk off
-#ifdef USE_HIP_EXPERIMENTS
-    if (!strcmp(name, "conv_v5_min_blocks")) { conv_v5_set_min_blocks((long)value); return USE_OK; }
-    if (!strcmp(name, "conv_v5_stagger")) { conv_v5_set_stagger((int)value); return USE_OK; }
-    if (!strcmp(name, "conv_v6")) { conv_v6_enable(value != 0); return USE_OK; }
-#endif
     return fail(USE_E_INVALID, "unknown option '%s'", name);
 }
 const char* use_last_error(void) { return g_err.c_str(); }
@@ -1304,6 +1301,13 @@ int use_profile_aux(use_handle* h, int index, char* name, int name_cap, int* H, 
     return USE_OK;
 }
 
+int use_profile_aux_flops(use_handle* h, int index, double* flops) {
+    if (!h) return fail(USE_E_INVALID, "null handle");
+    if (index < 0 || index >= (int)h->prof_aux.size()) return 1;
+    if (flops) *flops = h->prof_aux[(size_t)index].flops;
+    return USE_OK;
+}
+
 int use_timesteps(int N, float t_eps, float* out) {
     if (N < 1 || !out) return fail(USE_E_INVALID, "bad arguments");
     std::vector<float> ts; linspace_f32(1.0f, t_eps, N, ts);
@@ -1619,12 +1623,6 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             case 7: if (!conv_sk_eligible(a)) return -1; launch_conv_sk(a, 0); return 0;
             case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
             case 4: if (!a.wb || (XC && !a.w2b)) return -1; launch_conv_v4(a, 0); return 0;
-            case 8: if (!conv_v7_supports(a)) return -1; conv_v7_prepare(a.Cout, a.in_dtype); launch_conv_v7(a, 0); return 0;
-#ifdef USE_HIP_EXPERIMENTS
-            case 9: if (!conv_v8_supports(a)) return -1; launch_conv_v8(a, 0); return 0;      // (the weight copy is built on the first call)
-            case 5: if (!a.wb || (XC && !a.w2b) || dt == DT_F32) return -1; launch_conv_v5(a, 0); return 0;
-            case 6: if (!conv_v6_eligible(a)) return -1; launch_conv_v6(a, 0); return 0;
-#endif
             default: return -1;
         }
     };
@@ -1640,7 +1638,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
     if (trace) {
         unsigned long long hb[512];
         (void)hipMemcpy(hb, trace, sizeof hb, hipMemcpyDeviceToHost);
-        for (int g = 0; g < 2; ++g) {                           // wave 0 / wave 4 (conv_v4 / conv_v7 stamp both wave groups)
+        for (int g = 0; g < 2; ++g) {                           // wave 0 / wave 4 (conv_v4 stamps both wave groups)
             unsigned long long prev = hb[g * 256 + 1];
             for (int i = 0; i < 125 && hb[g * 256 + 2 * i]; ++i) {
                 fprintf(stderr, "[trace G%d] id %3llu  +%6llu  @%8llu\n", g, hb[g * 256 + 2 * i], hb[g * 256 + 2 * i + 1] - prev, hb[g * 256 + 2 * i + 1] - hb[1]);
@@ -1673,9 +1671,6 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             stats_host[i] = (float)((double)hs[i] / 1048576.0); stats_host[i + 1] = (float)((double)hs[i + 1] / 1048576.0);
         }
     }
-#ifdef USE_HIP_EXPERIMENTS
-    conv_v8_clear();                                          // its weight copies are keyed by the device pointers freed below
-#endif
     cleanup();
     return rc;
 }
@@ -1733,7 +1728,6 @@ int use_op_conv(const use_conv_op* c, use_stream_t stream) {
         case 2: if (!conv_v2_eligible(a)) rc = fail(USE_E_INVALID, "conv_v2 cannot run this case"); else launch_conv_v2(a, s); break;
         case 4: if (!slab || (XC && !slab2) || a.H % 16 || a.W % 32 || dt != odt) rc = fail(USE_E_INVALID, "conv_v4 cannot run this case"); else launch_conv_v4(a, s); break;
         case 7: if (!conv_sk_eligible(a)) rc = fail(USE_E_INVALID, "conv_sk cannot run this case"); else launch_conv_sk(a, s); break;
-        case 8: if (!conv_v7_supports(a)) rc = fail(USE_E_INVALID, "conv_v7 cannot run this case"); else { conv_v7_prepare(a.Cout, dt); launch_conv_v7(a, s); } break;
         default: rc = fail(USE_E_INVALID, "use_op_conv: unknown variant %d", c->variant);
     }
     if (hipStreamSynchronize(s) != hipSuccess && rc == USE_OK) rc = fail(USE_E_HIP, "use_op_conv: %s", hipGetErrorString(hipGetLastError()));

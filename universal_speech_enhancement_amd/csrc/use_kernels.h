@@ -31,9 +31,9 @@ struct ConvArgs {
     int act;                // 0: none, 1: SiLU (after the affine)
     const void* w;          // packed [CoutPad][ntaps][C0+C1] in in_dtype
     const void* wb;         // optional slab-major copy [ntaps][(C0+C1)/ck][CoutPad][ck], ck = conv_v4_chunk(in_dtype)
-                            // (one (tap, chunk) slab contiguous: conv_v4 / conv_v5), or null.  Rows are 64 bytes; the 16-byte
+                            // (one (tap, chunk) slab contiguous: conv_v4), or null.  Rows are 64 bytes; the 16-byte
                             // piece q of row n is stored at position q ^ ((n >> 2) & 3) (bank-conflict-free LDS image for
-                            // a lane-linear LDS-DMA copy, see use_conv_v5.hip)
+                            // a lane-linear copy: conv_v4 stores it as it is)
     int cout_pad;
     // optional second K segment: + conv1x1(concat(x0[XC0], x1[XC1])) with weights w2 [CoutPad][1][XC0+XC1]
     // (the res-block shortcut Conv_2 fused into Conv_1; raw input, no affine / activation)
@@ -51,7 +51,6 @@ struct ConvArgs {
     long long* stats;       // or null: [B][Cout][2] fixed-point totals (sum * 2^20, sum of squares * 2^20) of the stored values,
                             // accumulated with 64-bit integer atomics (order-independent, hence deterministic); zeroed by the caller
     int B, H, W, Cout, ntaps;
-    int stagger, stagger_lo, stagger_hi;   // conv_v5_kernel: workgroups [lo, hi) of the dispatch order start `stagger` x s_sleep(127) late
     int dbg;                // ablation bits for kernel bring-up (0 in production)
     unsigned long long* trace;   // optional: s_memtime stamps of workgroup 0 (kernel bring-up), else null
 };
@@ -62,49 +61,15 @@ void launch_conv_v2(const ConvArgs& a, hipStream_t s);
 // wide-tile variant (use_conv_v4.hip): 16x32-pixel tiles, K chunks of conv_v4_chunk() channels, slab-major weights
 inline int conv_v4_chunk(int dtype) { return dtype == DT_F32 ? 16 : 32; }
 inline int conv_v4_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 31) / 32); }
-// Measured-and-rejected schedules of the dominant convolution, built only with `make EXPERIMENTS=1` (scripts/experiments/):
-// conv_v5 = two 4-wave workgroups per CU (8x32-pixel tiles, LDS-DMA weights); conv_v6 = conv_v4's geometry with one barrier per
-// tap row, in-wave fragment prefetch and LDS-DMA weights.  Both are bit-identical to conv_v4 and no faster.
-inline int conv_v5_tiles(int H, int W) { return ((H + 7) / 8) * ((W + 31) / 32); }
-#ifdef USE_HIP_EXPERIMENTS
-bool conv_v5_eligible(const ConvArgs& a);
-void conv_v5_set_min_blocks(long n);                     // smallest per-image grid conv_v5 is used for
-void conv_v5_set_stagger(int n);                         // -1: automatic, 0: off, n: delay of the second resident workgroups
-void launch_conv_v5(const ConvArgs& a, hipStream_t s);
-bool conv_v6_eligible(const ConvArgs& a);
-void conv_v6_enable(bool on);
-void launch_conv_v6(const ConvArgs& a, hipStream_t s);
-#else
-inline bool conv_v5_eligible(const ConvArgs&) { return false; }
-inline bool conv_v6_eligible(const ConvArgs&) { return false; }
-#endif
 // split-K variant for the small maps (use_conv_sk.hip): 64-pixel x 32/64-channel tiles, the 8 waves of a workgroup split K
 bool conv_sk_eligible(const ConvArgs& a);
 void conv_sk_set_max_px(long n);                         // largest map (H*W) it is used for (default 16x20)
 void launch_conv_sk(const ConvArgs& a, hipStream_t s);
 void launch_conv_generic(const ConvArgs& a, hipStream_t s);   // conv_kernel / pyr_conv_kernel / conv_in_kernel only (no specialised schedule)
-void pyr_conv_set_pipe(int n);
-// (EXPERIMENTS build only) two-workgroups-per-CU form of the large-map 3x3 convolution (scripts/experiments/use_conv_v8.hip)
-bool conv_v8_supports(const ConvArgs& a);
-bool conv_v8_eligible(const ConvArgs& a);
-void conv_v8_prepare(const ConvArgs& a, hipStream_t s);      // builds the layer's chunk-major weight copy (never inside a stream capture)
-void launch_conv_v8(const ConvArgs& a, hipStream_t s);
-void conv_v8_set(int on);
-void conv_v8_set_min_blocks(long n);
-void conv_v8_clear();                           // pyramid-head convolution: workgroups per item of the pipelined form (0: off)
+void pyr_conv_set_pipe(int n);                          // pyramid-head convolution: workgroups per item of the pipelined form (0: off)
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 128 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);
-// persistent form of conv_v4 (use_conv_v7.hip): one workgroup per CU walks a range of tiles of one item with the next tile's first
-// halo chunk staged behind the current tile's last MFMAs; LDS-free epilogue (swapped MFMA operands); 16-bit storage, no fused shortcut / Combine
-bool conv_v7_supports(const ConvArgs& a);                 // the shapes / fusions the kernel implements
-bool conv_v7_eligible(const ConvArgs& a);                 // ... and large enough to be dispatched to it
-void conv_v7_set_modes(int m);                           // which convolutions go to it: bit 0 plain, 1 residual, 2 fused shortcut
-void conv_v7_set_units_per_wg(int n);                    // length of a workgroup's walk (0: even split over the CUs)
-void conv_v7_set_max_units(long n);
-void conv_v7_set_min_units(long n);                      // smallest per-image unit count (tiles x channel blocks) it is used for; 0: off
-void launch_conv_v7(const ConvArgs& a, hipStream_t s);
-void conv_v7_prepare(int cout, int dtype);               // builds the identity slabs a residual convolution needs (plan time, outside any capture)
 // GroupNorm finalisation for the consumers that take a coefficient array (FIR resampling kernels): per-(b, group) mean / rstd
 // from the per-channel totals of up to two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b): y = a*x + b.
 void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta,

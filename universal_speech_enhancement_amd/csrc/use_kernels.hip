@@ -861,12 +861,7 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
         if ((long)a.H * a.W >= lo && (long)a.H * a.W <= hi) return;
     }
 #endif
-#ifdef USE_HIP_EXPERIMENTS
-    if (conv_v5_eligible(a)) { launch_conv_v5(a, s); return; }
-    if (conv_v6_eligible(a)) { launch_conv_v6(a, s); return; }
-#endif
     if (conv_sk_eligible(a)) { launch_conv_sk(a, s); return; }
-    if (conv_v7_eligible(a)) { launch_conv_v7(a, s); return; }
     if (conv_v4_eligible(a)) { launch_conv_v4(a, s); return; }
     if (conv_v2_eligible(a)) { launch_conv_v2(a, s); return; }
     launch_conv_generic(a, s);

@@ -254,8 +254,10 @@ class HipScoreEngine:
         check(self.L.use_get_stat(self.h, name.encode(), C.byref(v)), "use_get_stat")
         return int(v.value)
 
-    def profile_aux(self):
-        """HBM-bound kernels of the last ``profile_score``: [(kernel class, H, W, algorithmic bytes, ms)] in launch order."""
+    def profile_aux(self, with_flops: bool = False):
+        """The other kernels of the last ``profile_score``: [(kernel class, H, W, algorithmic bytes, ms[, algorithmic FLOPs])] in launch
+        order - the HBM-bound classes (fir_up, fir_down, pyr_conv, conv_in: FLOPs 0) and the MFMA-bound ones beside the dominant kernel
+        (conv_v2, conv_sk)."""
         out, i = [], 0
         name = C.create_string_buffer(32)
         H, W, by, ms = C.c_int(), C.c_int(), C.c_double(), C.c_double()
@@ -264,7 +266,9 @@ class HipScoreEngine:
             if rc == 1:
                 return out
             check(rc, "use_profile_aux")
-            out.append((name.value.decode(), H.value, W.value, by.value, ms.value))
+            fl = C.c_double()
+            check(self.L.use_profile_aux_flops(self.h, i, C.byref(fl)), "use_profile_aux_flops")
+            out.append((name.value.decode(), H.value, W.value, by.value, ms.value) + ((fl.value,) if with_flops else ()))
             i += 1
 
     def set_sampler(self, N, predictor="reverse_diffusion", corrector="none", corrector_steps=1, snr=0.5, t_eps=3e-2,
