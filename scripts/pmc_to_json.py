@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 --pmc passes of scripts/run_pmc.sh for one kernel into the JSON that bench.py quotes.
+"""Summarise the rocprofv3 --pmc passes of scripts/profile.sh pmc for one kernel into the JSON that bench.py quotes.
 usage: pmc_to_json.py <pmc-dir> <kernel-substring> <out.json>
 HBM bytes follow MI355X_MICROARCH.md (HBM section): rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950
 FETCH_SIZE tallies 128-byte read requests at 64 B, so it is doubled."""
@@ -19,7 +19,7 @@ n = max(v[1] for v in acc.values())
 rd = avg.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0          # KB -> B, x2: gfx950 correction (see the guide's HBM section)
 wr = avg.get("WRITE_SIZE", 0.0) * 1024.0
 res = {
-    "kernel": filt, "workload": "one score evaluation at configs[1] (B=8, T'=640), scripts/run_pmc.sh",
+    "kernel": filt, "workload": "one score evaluation at configs[1] (B=8, T'=640), scripts/profile.sh pmc",
     "dispatches_averaged": n,
     "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
     "fetch_size_correction": "x2 (gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B for 128-B requests)",
