@@ -219,6 +219,14 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         // pieces are then transformed one by one as they arrive.
         V4_STAMP(12)
         uint4 w0 = zero4, raw[PIECE_ITERS];
+        // (GroupNorm affine and weights FIRST: VMEM returns in order, and the table of the affine is needed - behind a rendezvous - before
+        // the first piece can be transformed; the pieces are then transformed one by one as they arrive)
+        float2 cfv = make_float2(1.f, 0.f);                  // GroupNorm affine of input channel tid of this item
+        if (tid < Ctot)
+            cfv = p.gn_st0 ? gn_coef_of(p.gn_st0, p.C0, p.gn_st1, p.C1, p.gn_gamma, p.gn_beta, p.gn_groups, p.gn_inv_n, p.gn_eps, b, tid)
+                  : p.coef ? *reinterpret_cast<const float2*>(p.coef + ((size_t)b * Ctot + tid) * 2) : make_float2(1.f, 0.f);
+        V4_LOAD_W(0, 0, w0);
+        V4_LOAD_W(0, 1, wS);                                 // stored by LDS(0)
         int slot[PIECE_ITERS], ppv[PIECE_ITERS]; bool inbv[PIECE_ITERS];
 #pragma unroll
         for (int j = 0; j < PIECE_ITERS; ++j) {
@@ -240,12 +248,6 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
             ppv[j] = pp; inbv[j] = inb;
             if (idx >= NPIECE) slot[j] = -1;
         }
-        V4_LOAD_W(0, 0, w0);
-        V4_LOAD_W(0, 1, wS);                                 // stored by LDS(0)
-        float2 cfv = make_float2(1.f, 0.f);                  // GroupNorm affine of input channel tid of this item
-        if (tid < Ctot)
-            cfv = p.gn_st0 ? gn_coef_of(p.gn_st0, p.C0, p.gn_st1, p.C1, p.gn_gamma, p.gn_beta, p.gn_groups, p.gn_inv_n, p.gn_eps, b, tid)
-                  : p.coef ? *reinterpret_cast<const float2*>(p.coef + ((size_t)b * Ctot + tid) * 2) : make_float2(1.f, 0.f);
         __builtin_amdgcn_sched_barrier(0);                   // the loads above are issued before anything below
         V4_STAMP(13)
 #pragma unroll
