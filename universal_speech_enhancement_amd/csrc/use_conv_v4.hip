@@ -566,7 +566,10 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
                 red[(wave * BN + ch * CH + c) * 2] = st_s[c]; red[(wave * BN + ch * CH + c) * 2 + 1] = st_q[c];
             }
         }
-        __syncthreads();
+        // (not __syncthreads(): its release fence waits for the acknowledgement of this wave's 16 output stores - 2-3 k cycles in which
+        // the reduction and the atomics below can already run; only the LDS writes above have to have landed)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         if (tid < BN) {
             float s = 0.f, q = 0.f;
 #pragma unroll
