@@ -34,6 +34,8 @@ struct ConvArgs {
                             // (one (tap, chunk) slab contiguous: conv_v4), or null.  Rows are 64 bytes; the 16-byte
                             // piece q of row n is stored at position q ^ ((n >> 2) & 3) (bank-conflict-free LDS image for
                             // a lane-linear copy: conv_v4 stores it as it is)
+    const void* wc;         // optional 16-channel-chunk copy [(C0+C1)/16][ntaps][CoutPad][16] (conv_v9: one chunk's nine slabs of a
+                            // 128-channel block are nine contiguous 4 KB pieces - the image its LDS-DMA copies), 16-bit types only, or null
     int cout_pad;
     // optional second K segment: + conv1x1(concat(x0[XC0], x1[XC1])) with weights w2 [CoutPad][1][XC0+XC1]
     // (the res-block shortcut Conv_2 fused into Conv_1; raw input, no affine / activation)
@@ -70,6 +72,11 @@ void pyr_conv_set_pipe(int n);                          // pyramid-head convolut
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 128 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);
+// one-wave-per-SIMD persistent variant (use_conv_v9.hip, generated by gen_conv_v9.py): plain and residual 3x3 convolutions of the large maps
+bool conv_v9_eligible(const ConvArgs& a);
+void conv_v9_set_enable(int on);                         // default off
+void conv_v9_set_min_units(long n);                      // smallest launch (tiles x channel blocks x items) it is used for
+void launch_conv_v9(const ConvArgs& a, hipStream_t s);
 // GroupNorm finalisation for the consumers that take a coefficient array (FIR resampling kernels): per-(b, group) mean / rstd
 // from the per-channel totals of up to two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b): y = a*x + b.
 void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta,
