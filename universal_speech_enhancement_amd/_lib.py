@@ -125,6 +125,11 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
         _lib = L
+        # USE_HIP_OPTS="name=value,...": use_set_option calls at load time (A/B runs of the test suite and the bench with an option flipped)
+        for kv in filter(None, os.environ.get("USE_HIP_OPTS", "").split(",")):
+            k, v = kv.split("=")
+            if L.use_set_option(k.encode(), int(v)) < 0:
+                raise UseHipError(f"USE_HIP_OPTS: {kv}: " + L.use_last_error().decode(errors="replace"))
     return _lib
 
 
