@@ -443,7 +443,9 @@ template <> struct Mfma16<__bf16> {
 template <> struct Mfma16<_Float16> {
     DEVI static f32x4 mma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
-template <typename T16>
+// (round 4: ONEBLK / ACT as compile-time constants - with a run-time block index hipcc selected each of the 16 affine coefficients per
+// piece, 2 v_cndmask per staged element beside the 7.5 instructions of the transform itself)
+template <typename T16, bool ONEBLK, bool ACT>
 __global__ __launch_bounds__(256) void pyr_conv_pipe_kernel(ConvArgs p, int tiles_per_wg) {
     typedef Mfma<T16> MF;
     extern __shared__ __attribute__((aligned(16))) char psm[];
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(256) void pyr_conv_pipe_kernel(ConvArgs p, int tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z;
     const int tiles_x = (p.W + TILE_W - 1) / TILE_W, ntiles = tiles_x * ((p.H + TILE_H - 1) / TILE_H);
-    const int Cin = p.C0, nblk = Cin / PYR_CB;                // 1 or 2
+    const int Cin = p.C0, nblk = ONEBLK ? 1 : Cin / PYR_CB;   // 1 or 2
     const T16* src = (const T16*)p.src0;
     const int part = tid % PYR_PP;
     const int m = lane & 31;
@@ -526,8 +528,8 @@ __global__ __launch_bounds__(256) void pyr_conv_pipe_kernel(ConvArgs p, int tile
                 Vec16<T16>::load(reinterpret_cast<const T16*>(&rawC[j]), v);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    v[k] = fmaf(v[k], blk ? ca[1][k] : ca[0][k], blk ? cb[1][k] : cb[0][k]);
-                    if (p.act) v[k] = silu_f<false>(v[k]);
+                    v[k] = ONEBLK ? fmaf(v[k], ca[0][k], cb[0][k]) : fmaf(v[k], blk ? ca[1][k] : ca[0][k], blk ? cb[1][k] : cb[0][k]);
+                    if (ACT) v[k] = silu_f<false>(v[k]);
                 }
                 o = Vec16<T16>::pack(v);
             }
@@ -882,14 +884,21 @@ void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
         if (a.C0 <= 2 * PYR_CB && g_pyr_pipe) {              // pipelined form: <= 2 workgroups per CU worth of workgroups per item, several tiles each
             static bool attr2 = false;
             if (!attr2) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_pipe_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, PYRP_SMEM);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_pipe_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, PYRP_SMEM);
+#define USE_PYRP_ATTR(T, O, A) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_pipe_kernel<T, O, A>), hipFuncAttributeMaxDynamicSharedMemorySize, PYRP_SMEM);
+                USE_PYRP_ATTR(__bf16, true, true) USE_PYRP_ATTR(__bf16, true, false) USE_PYRP_ATTR(__bf16, false, true) USE_PYRP_ATTR(__bf16, false, false)
+                USE_PYRP_ATTR(_Float16, true, true) USE_PYRP_ATTR(_Float16, true, false) USE_PYRP_ATTR(_Float16, false, true) USE_PYRP_ATTR(_Float16, false, false)
+#undef USE_PYRP_ATTR
                 attr2 = true;
             }
             const int tpw = (ntiles + g_pyr_pipe - 1) / g_pyr_pipe;
             const dim3 grid((ntiles + tpw - 1) / tpw, 1, a.B);
-            if (a.in_dtype == DT_BF16) hipLaunchKernelGGL(pyr_conv_pipe_kernel<__bf16>, grid, dim3(256), PYRP_SMEM, s, a, tpw);
-            else                       hipLaunchKernelGGL(pyr_conv_pipe_kernel<_Float16>, grid, dim3(256), PYRP_SMEM, s, a, tpw);
+            const bool one = a.C0 == PYR_CB, act = a.act != 0;
+#define USE_PYRP_GO(T) { if (one && act) hipLaunchKernelGGL((pyr_conv_pipe_kernel<T, true, true>), grid, dim3(256), PYRP_SMEM, s, a, tpw);      \
+                         else if (one) hipLaunchKernelGGL((pyr_conv_pipe_kernel<T, true, false>), grid, dim3(256), PYRP_SMEM, s, a, tpw);         \
+                         else if (act) hipLaunchKernelGGL((pyr_conv_pipe_kernel<T, false, true>), grid, dim3(256), PYRP_SMEM, s, a, tpw);         \
+                         else hipLaunchKernelGGL((pyr_conv_pipe_kernel<T, false, false>), grid, dim3(256), PYRP_SMEM, s, a, tpw); }
+            if (a.in_dtype == DT_BF16) USE_PYRP_GO(__bf16) else USE_PYRP_GO(_Float16)
+#undef USE_PYRP_GO
             return;
         }
         if (a.in_dtype == DT_BF16) hipLaunchKernelGGL(pyr_conv_kernel<__bf16>, dim3(ntiles, 1, a.B), dim3(256), PYR_SMEM, s, a);
@@ -1091,16 +1100,22 @@ __global__ __launch_bounds__(256) void fir_up_blk_kernel(const T* __restrict__ s
 // Down x2, one thread per 2x2 OUTPUT block (8 or 4 channels): the block reads a 6x6 input neighbourhood, each input is
 // loaded and normalised + activated once per thread (36 per 4 outputs instead of 64), and the separable [1,3,3,1]/8
 // kernel is applied horizontally per input row, then vertically.
-template <typename T>
-__global__ __launch_bounds__(256) void fir_down_blk_kernel(const T* __restrict__ src, const float* __restrict__ coef,
-                                                           int act, T* __restrict__ out_act, T* __restrict__ out_raw,
+// (round 4: FAST = the hot configuration - activated + raw output, affine given, SiLU - with the flags as compile-time constants and the
+// column range check as a zero tap weight on a clamped address: with run-time flags hipcc computed both sides of `coef ? fma : v` and
+// `act ? silu : u` per element and selected the result of EVERY accumulation by the pixel's validity - 1 110 v_cndmask of 4 200 VALU
+// instructions per thread.  Same arithmetic in the same order: a tap weight of k4[t] * 1 is k4[t], and an excluded pixel adds 0.)
+template <typename T, bool FAST>
+__global__ __launch_bounds__(256) void fir_down_blk_kernel(const T* __restrict__ src, const float* __restrict__ coef_,
+                                                           int act_, T* __restrict__ out_act, T* __restrict__ out_raw,
                                                            int B, int H, int W, int C) {
     constexpr int VEC = Vec16<T>::N;
     constexpr bool ACC = sizeof(T) == 4;
     const int cv = C / VEC;
     const int OH = H / 2, OW = W / 2, BH = (OH + 1) / 2, BW = (OW + 1) / 2;
     const long total = (long)B * BH * BW * cv;
-    const bool want_act = out_act != nullptr;
+    const bool want_act = FAST ? true : out_act != nullptr;
+    const float* const coef = coef_;
+    const int act = FAST ? 1 : act_;
     const float k4[4] = {0.125f, 0.375f, 0.375f, 0.125f};
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c = (int)(idx % cv) * VEC;
@@ -1133,13 +1148,14 @@ __global__ __launch_bounds__(256) void fir_down_blk_kernel(const T* __restrict__
 #pragma unroll
             for (int e = 0; e < 6; ++e) {
                 const int x = x0 + e;
-                if (x < 0 || x >= W) continue;
+                const bool xok = x >= 0 && x < W;
+                if (!FAST && !xok) continue;
                 float v[VEC], u[VEC];
-                Vec16<T>::load(src + ((size_t)(b * H + y) * W + x) * C + c, v);
+                Vec16<T>::load(src + ((size_t)(b * H + y) * W + (FAST ? min(max(x, 0), W - 1) : x)) * C + c, v);
                 if (want_act) {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
-                        u[k] = coef ? fmaf(v[k], ca[k], cb[k]) : v[k];
+                        u[k] = (FAST || coef) ? fmaf(v[k], ca[k], cb[k]) : v[k];
                         if (act) u[k] = silu_f<ACC>(u[k]);
                     }
                 }
@@ -1147,10 +1163,11 @@ __global__ __launch_bounds__(256) void fir_down_blk_kernel(const T* __restrict__
                 for (int j = 0; j < 2; ++j) {
                     const int t = e - 2 * j;                 // tap index of this input column for output column j
                     if (t < 0 || t > 3) continue;
+                    const float wt = FAST ? (xok ? k4[t] : 0.f) : k4[t];
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
-                        hr[j][k] = fmaf(k4[t], v[k], hr[j][k]);
-                        if (want_act) ha[j][k] = fmaf(k4[t], u[k], ha[j][k]);
+                        hr[j][k] = fmaf(wt, v[k], hr[j][k]);
+                        if (want_act) ha[j][k] = fmaf(wt, u[k], ha[j][k]);
                     }
                 }
             }
@@ -1204,15 +1221,21 @@ static void fir_launch(const void* src, int dtype, const float* coef, int act, v
         int blocks = (int)((total + 255) / 256);
         if (blocks > 256 * 16) blocks = 256 * 16;
         if (blocks < 1) blocks = 1;
+        const bool fast = out_act && out_raw && coef && act;    // the res-block down-sampler of the network
         if (dtype == DT_F32)
-            hipLaunchKernelGGL((fir_down_blk_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)src, coef, act,
+            hipLaunchKernelGGL((fir_down_blk_kernel<float, false>), dim3(blocks), dim3(256), 0, s, (const float*)src, coef, act,
                                (float*)out_act, (float*)out_raw, B, H, W, C);
-        else if (dtype == DT_F16)
-            hipLaunchKernelGGL((fir_down_blk_kernel<_Float16>), dim3(blocks), dim3(256), 0, s, (const _Float16*)src, coef, act,
-                               (_Float16*)out_act, (_Float16*)out_raw, B, H, W, C);
-        else
-            hipLaunchKernelGGL((fir_down_blk_kernel<__bf16>), dim3(blocks), dim3(256), 0, s, (const __bf16*)src, coef, act,
-                               (__bf16*)out_act, (__bf16*)out_raw, B, H, W, C);
+        else if (dtype == DT_F16) {
+            if (fast) hipLaunchKernelGGL((fir_down_blk_kernel<_Float16, true>), dim3(blocks), dim3(256), 0, s, (const _Float16*)src, coef, act,
+                                         (_Float16*)out_act, (_Float16*)out_raw, B, H, W, C);
+            else hipLaunchKernelGGL((fir_down_blk_kernel<_Float16, false>), dim3(blocks), dim3(256), 0, s, (const _Float16*)src, coef, act,
+                                    (_Float16*)out_act, (_Float16*)out_raw, B, H, W, C);
+        } else {
+            if (fast) hipLaunchKernelGGL((fir_down_blk_kernel<__bf16, true>), dim3(blocks), dim3(256), 0, s, (const __bf16*)src, coef, act,
+                                         (__bf16*)out_act, (__bf16*)out_raw, B, H, W, C);
+            else hipLaunchKernelGGL((fir_down_blk_kernel<__bf16, false>), dim3(blocks), dim3(256), 0, s, (const __bf16*)src, coef, act,
+                                    (__bf16*)out_act, (__bf16*)out_raw, B, H, W, C);
+        }
     }
 }
 void launch_fir_up2(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
