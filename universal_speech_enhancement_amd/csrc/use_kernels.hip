@@ -445,6 +445,9 @@ template <> struct Mfma16<_Float16> {
 };
 // (round 4: ONEBLK / ACT as compile-time constants - with a run-time block index hipcc selected each of the 16 affine coefficients per
 // piece, 2 v_cndmask per staged element beside the 7.5 instructions of the transform itself)
+#ifndef USE_PYR_ABL
+#define USE_PYR_ABL 0                /* timing-only ablations: 1 no transform, 2 no MFMAs, 4 no residual / bias loads in the epilogue */
+#endif
 template <typename T16, bool ONEBLK, bool ACT>
 __global__ __launch_bounds__(256) void pyr_conv_pipe_kernel(ConvArgs p, int tiles_per_wg) {
     typedef Mfma<T16> MF;
@@ -491,65 +494,87 @@ __global__ __launch_bounds__(256) void pyr_conv_pipe_kernel(ConvArgs p, int tile
         }
     const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
     const int nunits = (t_end - t_begin) * nblk;
-    uint4 rawN[NP]; int dstN[NP];
-    auto prefetch = [&](int u) {                             // unit u = (tile, block): issue its halo loads
+    // Round 4: branch-free staging.  The thread's NP pieces are the same halo positions in every unit: their byte offset relative to the
+    // tile origin, their LDS destination and their (hy, hx) are computed once; a unit adds a scalar base and turns "outside the image"
+    // into an out-of-range buffer offset (the load returns 0, no divergent branch) and a zeroed result; pieces beyond the halo
+    // (the last, partial round) load nothing and store to spare bytes of the halo's first row.  Two register sets alternate, so the
+    // raw pieces are never copied.  Same arithmetic, same order as before.
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T16*>(src) + (size_t)b * p.H * p.W * Cin, 0,
+                                                                             (unsigned)((size_t)p.H * p.W * Cin * 2), 0x00020000);
+    int rel[NP], dbase[NP]; unsigned hyx[NP];
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) {
+        const int idx = jj * 256 + tid, pix = idx / PYR_PP;
+        const int hy = pix / (TILE_W + 2), hx = pix - hy * (TILE_W + 2);
+        const bool have = pix < (TILE_H + 2) * (TILE_W + 2);
+        rel[jj] = (((hy - 1) * p.W + (hx - 1)) * Cin + part * 8) * 2;
+        dbase[jj] = have ? hy * PYR_HPITCH + hx * PYR_ROWB + part * 16 : (TILE_W + 2) * PYR_ROWB + (tid & 7) * 16;
+        hyx[jj] = have ? (unsigned)(hy << 8 | hx) : 0xff00u;
+    }
+    static_assert((TILE_W + 2) * PYR_ROWB + 8 * 16 <= PYR_HPITCH, "spare bytes behind a halo row");
+    auto prefetch = [&](int u, uint4 (&raw)[NP], unsigned& ok) {   // unit u = (tile, block): issue its halo loads
+        u = min(u, nunits - 1);                                    // (past the end: the last unit again - unconditional loads keep hipcc's counted waits)
         const int tile = t_begin + u / nblk, c0 = (u % nblk) * PYR_CB;
         const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
+        const int base = ((ty0 * p.W + tx0) * Cin + c0) * 2;
+        ok = 0u;
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int idx = j * 256 + tid, pix = idx / PYR_PP;
-            const int hy = pix / (TILE_W + 2), hx = pix - hy * (TILE_W + 2);
-            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-            const bool have = pix < (TILE_H + 2) * (TILE_W + 2);
-            const bool inb = have && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            dstN[j] = have ? (inb ? 1 : 2) * 0x100000 + hy * PYR_HPITCH + hx * PYR_ROWB + part * 16 : 0;
-            rawN[j] = inb ? *reinterpret_cast<const uint4*>(src + ((size_t)(b * p.H + gy) * p.W + gx) * Cin + c0 + part * 8)
-                          : make_uint4(0, 0, 0, 0);
+        for (int jj = 0; jj < NP; ++jj) {
+            const int gy = ty0 + (int)(hyx[jj] >> 8) - 1, gx = tx0 + (int)(hyx[jj] & 255u) - 1;
+            const bool inb = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            ok |= inb ? 1u << jj : 0u;
+            raw[jj] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, inb ? (unsigned)(rel[jj] + base) : 0xfffffff0u, 0, 0));
         }
     };
-    if (nunits > 0) prefetch(0);
     f32x4 acc0, acc1;                                        // the wave's two 16-pixel rows
-    for (int u = 0; u < nunits; ++u) {
-        const int blk = u % nblk;
+    auto process = [&](int u, const uint4 (&raw)[NP], const unsigned ok) {
+        const int blk = ONEBLK ? 0 : u % nblk;
         if (blk == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
         }
-        uint4 rawC[NP]; int dstC[NP];
+        // the epilogue's residual (the incoming pyramid, fp32 [px][4]) is fetched now, behind the transform and the MFMAs (round 4:
+        // loaded where it was used it cost 31 of the kernel's 191 us)
+        const int tile_e = t_begin + u / nblk;
+        const int ty0e = (tile_e / tiles_x) * TILE_H, tx0e = (tile_e % tiles_x) * TILE_W;
+        const int gye = ty0e + (tid >> 4), gxe = tx0e + (tid & 15);
+        const bool out_ok = blk == nblk - 1 && tid < TILE_H * TILE_W && gye < p.H && gxe < p.W;
+        const size_t pixe = (size_t)(b * p.H + (out_ok ? gye : 0)) * p.W + (out_ok ? gxe : 0);
+        float rese[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.res && p.Cout == 4 && !(USE_PYR_ABL & 4)) {
+            const float4 r4 = *reinterpret_cast<const float4*>((const float*)p.res + pixe * 4);
+            rese[0] = r4.x; rese[1] = r4.y; rese[2] = r4.z; rese[3] = r4.w;
+        } else if (p.res && !(USE_PYR_ABL & 4)) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) { rawC[j] = rawN[j]; dstC[j] = dstN[j]; }
-        if (u + 1 < nunits) prefetch(u + 1);                  // in flight behind this unit's transform + MFMAs
+            for (int c = 0; c < 4; ++c) if (c < p.Cout) rese[c] = ((const float*)p.res)[pixe * p.Cout + c];
+        }
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            if (!dstC[j]) continue;
-            uint4 o = make_uint4(0, 0, 0, 0);                // outside the image: the conv's zero padding
-            if (dstC[j] < 0x200000) {
-                float v[8];
-                Vec16<T16>::load(reinterpret_cast<const T16*>(&rawC[j]), v);
+        for (int jj = 0; jj < NP; ++jj) {
+            float v[8];
+            Vec16<T16>::load(reinterpret_cast<const T16*>(&raw[jj]), v);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    v[k] = ONEBLK ? fmaf(v[k], ca[0][k], cb[0][k]) : fmaf(v[k], blk ? ca[1][k] : ca[0][k], blk ? cb[1][k] : cb[0][k]);
-                    if (ACT) v[k] = silu_f<false>(v[k]);
-                }
-                o = Vec16<T16>::pack(v);
+            for (int k = 0; k < 8; ++k) {
+                v[k] = ONEBLK ? fmaf(v[k], ca[0][k], cb[0][k]) : fmaf(v[k], blk ? ca[1][k] : ca[0][k], blk ? cb[1][k] : cb[0][k]);
+                if (ACT && !(USE_PYR_ABL & 1)) v[k] = silu_f<false>(v[k]);
             }
-            *reinterpret_cast<uint4*>(s_halo + (dstC[j] & 0xfffff)) = o;
+            uint4 o = (USE_PYR_ABL & 1) ? raw[jj] : Vec16<T16>::pack(v);
+            const unsigned mk = ((ok >> jj) & 1u) ? 0xffffffffu : 0u;    // outside the image: the conv's zero padding
+            o.x &= mk; o.y &= mk; o.z &= mk; o.w &= mk;
+            *reinterpret_cast<uint4*>(s_halo + dbase[jj]) = o;
         }
         __syncthreads();
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < ((USE_PYR_ABL & 2) ? 1 : 9); ++tap) {
             const char* ha = s_halo + a_base + (tap / 3) * PYR_HPITCH + (tap % 3) * PYR_ROWB;
             const char* wb = s_w + blk * PYR_WB + b_base + tap * 4 * PYR_ROWB;
 #pragma unroll
-            for (int kk = 0; kk < PYR_CB / 32; ++kk) {
+            for (int kk = 0; kk < ((USE_PYR_ABL & 2) ? 1 : PYR_CB / 32); ++kk) {
                 const auto wf = MF::ld(wb + kk * 64);
                 acc0 = Mfma16<T16>::mma(MF::ld(ha + kk * 64), wf, acc0);
                 acc1 = Mfma16<T16>::mma(MF::ld(ha + PYR_HPITCH + kk * 64), wf, acc1);
             }
         }
         if (blk == nblk - 1) {                                // tile complete: [128 px][4] through LDS, one pixel per thread
-            const int tile = t_begin + u / nblk;
-            const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
             if ((lane & 15) < 4) {                           // D of 16x16x32: column lane & 15 (output channel), rows 4 (lane >> 4) + r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -559,26 +584,30 @@ __global__ __launch_bounds__(256) void pyr_conv_pipe_kernel(ConvArgs p, int tile
                 }
             }
             __syncthreads();                                  // also: every wave is done with the halo
-            if (tid < TILE_H * TILE_W) {
-                const int gy = ty0 + (tid >> 4), gx = tx0 + (tid & 15);
-                if (gy < p.H && gx < p.W) {
-                    const size_t pix = (size_t)(b * p.H + gy) * p.W + gx;
-                    float4 v = *reinterpret_cast<const float4*>(s_out + tid * 4);
-                    float o[4] = {v.x, v.y, v.z, v.w};
+            if (out_ok) {
+                float4 v = *reinterpret_cast<const float4*>(s_out + tid * 4);
+                float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) if (c < p.Cout && p.bias) o[c] += p.bias[c];
-                    if (p.res) {
-                        const float* rp = (const float*)p.res + pix * p.Cout;
+                for (int c = 0; c < 4; ++c) if (c < p.Cout && p.bias && !(USE_PYR_ABL & 4)) o[c] += p.bias[c];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) if (c < p.Cout) o[c] += rp[c];
-                    }
-                    float* op = (float*)p.out + pix * p.Cout;
+                for (int c = 0; c < 4; ++c) o[c] += rese[c];
+                float* op = (float*)p.out + pixe * p.Cout;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) if (c < p.Cout) op[c] = o[c] * p.out_scale;
-                }
+                for (int c = 0; c < 4; ++c) if (c < p.Cout) op[c] = o[c] * p.out_scale;
             }
         } else {
             __syncthreads();                                  // every wave is done with the halo of this block
+        }
+    };
+    if (nunits <= 0) return;
+    uint4 rawA[NP], rawB[NP]; unsigned okA = 0u, okB = 0u;
+    prefetch(0, rawA, okA);
+    for (int u = 0; u < nunits; u += 2) {
+        prefetch(u + 1, rawB, okB);                           // in flight behind this unit's transform + MFMAs
+        process(u, rawA, okA);
+        if (u + 1 < nunits) {
+            prefetch(u + 2, rawA, okA);
+            process(u + 1, rawB, okB);
         }
     }
 }
