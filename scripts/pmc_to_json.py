@@ -37,6 +37,23 @@ if "TCC_HIT_sum" in avg and "TCC_MISS_sum" in avg:
     res["l2_hit_rate"] = avg["TCC_HIT_sum"] / (avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])
 if "SQ_LDS_BANK_CONFLICT" in avg and "SQ_LDS_IDX_ACTIVE" in avg:
     res["lds_bank_conflict_frac_of_lds"] = avg["SQ_LDS_BANK_CONFLICT"] / avg["SQ_LDS_IDX_ACTIVE"]
+# effective shader clock while the kernel runs: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the kernel's duration in the kernel trace of
+# the SAME pass (PMC passes serialise dispatches, so the duration is the kernel alone on the chip)
+gtot, ttot = 0.0, 0.0
+for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+    rows = [r for r in csv.DictReader(open(f)) if filt in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
+    if not rows:
+        continue
+    tr = f.replace("counter_collection.csv", "kernel_trace.csv")
+    if not os.path.exists(tr):
+        continue
+    dur = {r["Dispatch_Id"]: float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(tr)) if filt in r["Kernel_Name"]}
+    for r in rows:
+        if r["Dispatch_Id"] in dur:
+            gtot += float(r["Counter_Value"]); ttot += dur[r["Dispatch_Id"]]
+if ttot > 0:
+    res["effective_clock_GHz"] = gtot / 8.0 / ttot
+    res["effective_clock_note"] = "GRBM_GUI_ACTIVE / 8 XCDs / kernel-trace duration of the same (counter) pass; dispatches are serialised under --pmc"
 # provenance: bench.py quotes hbm_bytes_per_launch only while the kernel source is the one these counters were collected on
 import hashlib
 _src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "universal_speech_enhancement_amd", "csrc", "use_conv_v4.hip")

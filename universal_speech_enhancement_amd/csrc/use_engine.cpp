@@ -1643,7 +1643,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             case 1: launch_conv_generic(a, 0); return 0;
             case 7: if (!conv_sk_eligible(a)) return -1; launch_conv_sk(a, 0); return 0;
             case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
-            case 4: if (!a.wb || (XC && !a.w2b)) return -1; launch_conv_v4(a, 0); return 0;
+            case 4: if (!a.wb || (XC && !a.w2b) || a.H % 16 || a.W % 32) return -1; launch_conv_v4(a, 0); return 0;   // (conv_v4 has no partial tiles)
             case 9: { conv_v9_set_enable(1); conv_v9_set_min_units(1); const bool ok = conv_v9_eligible(a); if (ok) launch_conv_v9(a, 0); conv_v9_set_enable(0); conv_v9_set_min_units(320); return ok ? 0 : -1; }
             default: return -1;
         }
