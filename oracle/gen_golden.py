@@ -194,6 +194,34 @@ def gen_samplers():
                  noise_seed=33, n_draws=ndraw, N=7, corrector_steps=2, snr=0.5, eps=0.03)
 
 
+def gen_samplers_pf():
+    """get_pc_sampler(..., probability_flow=True) through the reference's own sampler.  The flag reaches Predictor.__init__, which stores
+    it and builds its reverse SDE as sde.reverse(score_fn) - without it (predictors.py:17) - so the outputs are those of the ordinary
+    reverse SDE; the fixture pins exactly that (the ODE form of sdes.py:136-141, 165-172 is only reached by get_ode_sampler)."""
+    Y = torch.from_numpy(tnoise.complex_normal(21, "samp_y", (3, 1, 16, 8)))
+    A = torch.from_numpy(tnoise.complex_normal(21, "samp_a", (1, 1, 16, 8)))
+
+    def score_fn(x, t, *args, score_conditioning=None, sde_input=None):
+        cond = sde_input if sde_input is not None else (args[0] if args else (score_conditioning if score_conditioning is not None else Y))
+        if isinstance(cond, (list, tuple)):
+            cond = cond[0]
+        return -(x - 0.8 * cond) / (0.1 + t[:, None, None, None] ** 2) + 0.05 * A * torch.tanh(x.abs())
+
+    for pred in ("reverse_diffusion", "euler_maruyama"):
+        sde = OUVESDE(); sde.N = 7
+        ndraw = 1 + 7 * 3
+        draws = tnoise.sampler_noise(35, ndraw, tuple(Y.shape))
+        orig = torch.randn_like
+        torch.randn_like = _Replay(list(draws))
+        try:
+            x, nfe = ref_sampling.get_pc_sampler(pred, "langevin", sde=sde, score_fn=score_fn, y=Y, eps=0.03, snr=0.5, corrector_steps=2,
+                                                 probability_flow=True, conditioning=[Y])()
+        finally:
+            torch.randn_like = orig
+        np.savez(os.path.join(OUT, f"sampler_pf_{pred}.npz"), Y=Y.numpy(), A=A.numpy(), x=x.numpy(), nfe=nfe,
+                 noise_seed=35, n_draws=ndraw, N=7, corrector_steps=2, snr=0.5, eps=0.03)
+
+
 def gen_samplers_em():
     """EulerMaruyamaPredictor (sampling/predictors.py:40-53 over RSDE.sde / rsde_parts, sdes.py:119-157).  On the reference's
     own predict path this predictor raises (rsde_parts calls score_model(x, t, conditioning) without sde_input, sdes.py:128);
@@ -547,7 +575,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    small = {"fir": gen_fir, "resblocks": gen_resblocks, "resblock_grads": gen_resblock_grads, "attn": gen_attn, "attn_grads": gen_attn_grads, "samplers": gen_samplers, "samplers_em": gen_samplers_em,
+    small = {"fir": gen_fir, "resblocks": gen_resblocks, "resblock_grads": gen_resblock_grads, "attn": gen_attn, "attn_grads": gen_attn_grads, "samplers": gen_samplers, "samplers_em": gen_samplers_em, "samplers_pf": gen_samplers_pf,
              "refine": gen_refine, "forward_small": gen_forward_small, "both": gen_both,
              "train_loss": gen_train_loss, "train_grads": gen_train_grads}
     big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1,

@@ -295,6 +295,26 @@ def test_euler_maruyama_kernels_match_reference_sampler(golden_dir, corr):
     np.testing.assert_allclose(x.cpu().numpy(), g["x"], rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("pred", ["reverse_diffusion", "euler_maruyama"])
+def test_probability_flow_update_kernels_match_reference_sampler(golden_dir, pred):
+    """probability_flow=True through the registries' seam path: accepted and - as in the reference, whose Predictor drops the flag
+    (predictors.py:17) - without effect on the updates; against the reference's own sampler output with the flag set."""
+    from universal_speech_enhancement_amd.sgmse import sampling
+    from universal_speech_enhancement_amd.sgmse.sdes import OUVESDE
+    g = dict(np.load(os.path.join(golden_dir, f"sampler_pf_{pred}.npz")))
+    Y, A = torch.from_numpy(g["Y"]).cuda(), torch.from_numpy(g["A"]).cuda()
+    draws = torch.from_numpy(tnoise.sampler_noise(int(g["noise_seed"]), int(g["n_draws"]), tuple(Y.shape))).cuda()
+
+    def score_fn(x, t, *args, score_conditioning=None, sde_input=None):
+        return -(x - 0.8 * Y) / (0.1 + t[:, None, None, None] ** 2) + 0.05 * A * torch.tanh(x.abs())
+
+    sde = OUVESDE(); sde.N = int(g["N"])
+    x, nfe = sampling.get_pc_sampler(pred, "langevin", sde=sde, score_fn=score_fn, y=Y, eps=float(g["eps"]), snr=float(g["snr"]),
+                                     corrector_steps=int(g["corrector_steps"]), probability_flow=True, conditioning=[Y], noise=draws)()
+    assert nfe == int(g["nfe"])
+    np.testing.assert_allclose(x.cpu().numpy(), g["x"], rtol=2e-4, atol=2e-5)
+
+
 def test_euler_maruyama_equals_reverse_diffusion_update():
     """For the OUVE SDE the two predictors are the same map up to rounding (f dt, g sqrt(dt))."""
     from universal_speech_enhancement_amd.sgmse.sampling import _sde_engine

@@ -57,6 +57,24 @@ def test_sampler_matches_reference(golden_dir, corr):
     np.testing.assert_allclose(x.numpy(), g["x"], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("pred", ["reverse_diffusion", "euler_maruyama"])
+def test_probability_flow_sampler_matches_reference(golden_dir, pred):
+    """get_pc_sampler(probability_flow=True) in the reference changes NOTHING: Predictor.__init__ stores the flag and builds its reverse
+    SDE as sde.reverse(score_fn) (predictors.py:17), so both predictors run the ordinary reverse SDE.  Pinned by outputs of the
+    reference's own sampler with the flag set (Langevin corrector x2 in between): the oracle - which has no such flag - reproduces them."""
+    g = _load(golden_dir, f"sampler_pf_{pred}.npz")
+    Y, A = torch.from_numpy(g["Y"]), torch.from_numpy(g["A"])
+    draws = tnoise.sampler_noise(int(g["noise_seed"]), int(g["n_draws"]), tuple(Y.shape))
+
+    def score(x, t):
+        return -(x - 0.8 * Y) / (0.1 + t[:, None, None, None] ** 2) + 0.05 * A * torch.tanh(x.abs())
+
+    x, nfe = so.pc_sampler(score, Y, int(g["N"]), pred, "langevin", int(g["corrector_steps"]), float(g["snr"]), float(g["eps"]),
+                           so.NoiseSource(replay=[torch.from_numpy(d) for d in draws]))
+    assert nfe == int(g["nfe"])
+    np.testing.assert_allclose(x.numpy(), g["x"], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("corr", ["none", "langevin"])
 def test_euler_maruyama_sampler_matches_reference(golden_dir, corr):
     """Row a8: EulerMaruyamaPredictor.update_fn + RSDE.sde / rsde_parts, pinned by outputs of the reference's own sampler."""

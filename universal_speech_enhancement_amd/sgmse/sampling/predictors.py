@@ -17,7 +17,7 @@ class Predictor(abc.ABC):
     def __init__(self, sde, score_fn, probability_flow=False):
         super().__init__()
         self.sde = sde
-        self.rsde = sde.reverse(score_fn, probability_flow) if hasattr(sde, "reverse") else None
+        self.rsde = sde.reverse(score_fn) if hasattr(sde, "reverse") else None       # (sic: the reference drops probability_flow here, predictors.py:17)
         self.score_fn = score_fn
         self.probability_flow = probability_flow
 
@@ -49,10 +49,10 @@ class _HipPredictor(Predictor):
 
     def update_fn(self, x, t, *args, noise=None, seed=0, **kwargs):
         from . import _sde_engine
-        if self.probability_flow:
-            raise NotImplementedError("probability-flow updates are not part of the predict path")
         y = args[0]
         score = _eval_score(self.score_fn, x, t, args, kwargs)
+        # (probability_flow: stored and, exactly as in the reference, without effect on the update - Predictor.__init__ builds its
+        # reverse SDE as sde.reverse(score_fn), predictors.py:17; pinned by tests/golden/sampler_pf_*.npz)
         return _sde_engine(self.sde, x.device).sde_predictor(self.hip_name, _uniform_t(t), self.sde.N, x, y, score,
                                                              noise=noise, seed=seed)
 
