@@ -11,10 +11,11 @@ Per chunk and wave: 48 fragment reads (36 weight + 12 pixel), 9 LDS-DMA weight l
 
 MFMAs + VALU are asm statements (hipcc would move them), memory operations are compiler-visible (volatile) so that hipcc's waitcnt
 insertion counts them.  MODE bits switch parts off: 1 fragment reads, 2 weight DMA, 4 halo loads + stores, 8 transform, 16 barrier."""
-import sys
+import sys, os
+TWO = int(os.environ.get("V9_TWO", "0"))
 
 HB = [0, 11264]                     # halo buffers: 10 x 34 px x 32 B = 10880
-WB = [22528, 22528 + 36864]         # weight buffers: 9 taps x 128 co x 32 B
+WB = [22528, 22528 + (0 if TWO else 36864)]   # weight buffers: 9 taps x 128 co x 32 B (TWO: aliased - timing only)
 LDS = WB[1] + 36864
 
 LO = 'v_lshlrev_b32 %[xl], 16, %[d]'
@@ -53,11 +54,12 @@ def window(b):
     # fragment reads in the order of need: for sequence positions 1..8 of this window and position 0 of the next one (tap 8 of chunk nb)
     mem = [[] for _ in range(72)]
     g_next = 0
-    for pos in list(range(1, 9)) + [9]:          # ring slot pos % 3 is free once position pos - 3 is done: not before gap (pos - 2) * 8
+    R = 2 if TWO else 3
+    for pos in list(range(1, 9)) + [9]:          # ring slot pos % R is free once position pos - R is done: not before gap (pos - R + 1) * 8
         t, buf = (seq[pos] if pos < 9 else (8, nb))
-        g_next = max(g_next, (pos - 2) * 8)
+        g_next = max(g_next, (pos - R + 1) * 8)
         for j in range(4):
-            mem[g_next].append(f'if (!(MODE & 1)) wf[{pos % 3}][{j}] = LDSV(wbase + {WB[buf] + (t * 128 + j * 32) * 32});'); g_next += 1
+            mem[g_next].append(f'if (!(MODE & 1)) wf[{pos % R}][{j}] = LDSV(wbase + {WB[buf] + (t * 128 + j * 32) * 32});'); g_next += 1
         for (r, dx) in newx[t]:
             mem[g_next].append(f'if (!(MODE & 1)) xf[{r * 3 + dx}] = LDSV(xbase + {HB[buf] + (r * 34 + dx) * 32});'); g_next += 1
     for q, g in enumerate(DMA_GAPS):
@@ -71,7 +73,7 @@ def window(b):
         t = seq[gi][0]
         i, j = k8 // 4, k8 % 4
         ops = f'[acc] "+a"(acc[{i}][{j}])'
-        ins = f'[w] "v"(wf[{gi % 3}][{j}]), [x] "v"(xf[{xidx(i, t)}])'
+        ins = f'[w] "v"(wf[{gi % (2 if TWO else 3)}][{j}]), [x] "v"(xf[{xidx(i, t)}])'
         bare = f'asm volatile("v_mfma_f32_32x32x16_bf16 %[acc], %[w], %[x], %[acc]" : {ops} : {ins});'
         n = g - XF_FIRST
         if 0 <= n < 60:
@@ -92,12 +94,14 @@ def window(b):
     return L
 
 
+WPEV = 2 if TWO else 1
 out = f'''// GENERATED by gen_v9_steady.py - do not edit.  hipcc --offload-arch=gfx950 -O3 v9_steady.hip -o v9_steady
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#define WPE {WPEV}
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) char lds_char;
@@ -108,7 +112,7 @@ typedef __attribute__((address_space(3))) volatile u32x4 lds_vu4;
 #define DMA(SO, LOFF) {{ char* dst_ = smem + (LOFF) + wave * 1024; __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)dst_, 16, wvoff, (SO), 0, 0); }}
 
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void v9_steady(const void* gx, const void* gw, float* sink, unsigned long long* cyc, int nwin, unsigned xbytes, unsigned wbytes) {{
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -163,13 +167,13 @@ template <int MODE> static void run(const char* what, const void* gx, const void
     for (int rep = 0; rep < 4; ++rep) {
         hipMemset(cyc, 0, 64);
         hipEventRecord(e0);
-        for (int l = 0; l < 5; ++l) hipLaunchKernelGGL(v9_steady<MODE>, dim3(256), dim3(256), ''' + str(LDS) + ''', 0, gx, gw, sink, cyc, nwin, xb, wb);
+        for (int l = 0; l < 5; ++l) hipLaunchKernelGGL(v9_steady<MODE>, dim3(''' + str(512 if TWO else 256) + '''), dim3(256), ''' + str(LDS) + ''', 0, gx, gw, sink, cyc, nwin, xb, wb);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5.f;
         if (rep && ms < best) best = ms;
     }
     unsigned long long h[4]; hipMemcpy(h, cyc, 32, hipMemcpyDeviceToHost);
-    const double flops = 256.0 * 4 * (double)nwin * 72 * 32768.0;
+    const double flops = ''' + str(512.0 if TWO else 256.0) + ''' * 4 * (double)nwin * 72 * 32768.0;
     printf("%-44s %8.3f ms  %7.1f TFLOP/s   %7.1f cycles per 72-MFMA window (ideal 2304)  clock %.2f GHz\\n", what, best, flops / best * 1e-9,
            (double)h[0] / nwin, (double)h[0] / (best * 1e6));
 }
@@ -196,4 +200,4 @@ int main() {
     return 0;
 }
 '''
-open(sys.argv[1] if len(sys.argv) > 1 else "scripts/microbench/v9_steady.hip", "w").write(out)
+open(sys.argv[1] if len(sys.argv) > 1 else ("scripts/microbench/v9_steady2.hip" if TWO else "scripts/microbench/v9_steady.hip"), "w").write(out)
