@@ -13,9 +13,10 @@ cases = {
     "cout 256":    (16, 64, 256, 0, 256, 0, 0, 1, 1, 1, 0),
 }
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+VAR = int(sys.argv[2]) if len(sys.argv) > 2 else 9
 for name, case in cases.items():
     ref = g.run(case, 1, 1, B, 1)
-    got = g.run(case, 9, 1, B, 1)
+    got = g.run(case, VAR, 1, B, 1)
     v4 = g.run(case, 4, 1, B, 1)
     if v4 is not None:
         d4 = np.abs(v4[0] - ref[0]); print(f"   [v4 vs generic: maxdiff {d4.max():.3g}, differing {np.mean(d4 > 0):.4f}; v9 vs generic differing {np.mean(np.abs(got[0] - ref[0]) > 0):.4f}; v9 vs v4 maxdiff {np.abs(got[0] - v4[0]).max():.3g} differing {np.mean(np.abs(got[0] - v4[0]) > 0):.4f}]")

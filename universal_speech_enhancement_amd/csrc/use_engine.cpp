@@ -931,6 +931,9 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
     if (!strcmp(name, "conv_v9")) { conv_v9_set_enable((int)value); return USE_OK; }
     if (!strcmp(name, "conv_v9_min_units")) { conv_v9_set_min_units((long)value); return USE_OK; }
+    if (!strcmp(name, "conv_v10")) { conv_v10_set_enable((int)value); return USE_OK; }
+    if (!strcmp(name, "conv_v10_min_units")) { conv_v10_set_min_units((long)value); return USE_OK; }
+    if (!strcmp(name, "conv_v10_strip")) { conv_v10_set_strip((int)value); return USE_OK; }
     if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_mfma16")) { wgrad_set_mfma16((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_blocks")) { wgrad_set_blocks((int)value); return USE_OK; }
@@ -1645,6 +1648,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
             case 4: if (!a.wb || (XC && !a.w2b) || a.H % 16 || a.W % 32) return -1; launch_conv_v4(a, 0); return 0;   // (conv_v4 has no partial tiles)
             case 9: { conv_v9_set_enable(1); conv_v9_set_min_units(1); const bool ok = conv_v9_eligible(a); if (ok) launch_conv_v9(a, 0); conv_v9_set_enable(0); conv_v9_set_min_units(320); return ok ? 0 : -1; }
+            case 10: { conv_v10_set_enable(1); conv_v10_set_min_units(1); const bool ok = conv_v10_eligible(a); if (ok) launch_conv_v10(a, 0); conv_v10_set_enable(0); conv_v10_set_min_units(320); return ok ? 0 : -1; }
             default: return -1;
         }
     };

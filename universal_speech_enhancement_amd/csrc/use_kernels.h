@@ -77,6 +77,12 @@ bool conv_v9_eligible(const ConvArgs& a);
 void conv_v9_set_enable(int on);                         // default off
 void conv_v9_set_min_units(long n);                      // smallest launch (tiles x channel blocks x items) it is used for
 void launch_conv_v9(const ConvArgs& a, hipStream_t s);
+// two co-resident 4-wave workgroups per CU running conv_v9's generated MFMA stream, non-persistent (use_conv_v10.hip, gen_conv_v10.py)
+bool conv_v10_eligible(const ConvArgs& a);
+void conv_v10_set_enable(int on);                        // default off
+void conv_v10_set_min_units(long n);
+void conv_v10_set_strip(int n);                          // tiles per workgroup
+void launch_conv_v10(const ConvArgs& a, hipStream_t s);
 // GroupNorm finalisation for the consumers that take a coefficient array (FIR resampling kernels): per-(b, group) mean / rstd
 // from the per-channel totals of up to two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b): y = a*x + b.
 void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta,
