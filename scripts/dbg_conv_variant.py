@@ -1,4 +1,5 @@
-"""conv_v9 bring-up: compare with the generic kernel on small shapes and print where the outputs differ."""
+"""Bring-up of a convolution variant (argv: batch, variant; default 10): compare with the generic kernel on small shapes and print where
+the outputs differ."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +14,7 @@ cases = {
     "cout 256":    (16, 64, 256, 0, 256, 0, 0, 1, 1, 1, 0),
 }
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-VAR = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+VAR = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 for name, case in cases.items():
     ref = g.run(case, 1, 1, B, 1)
     got = g.run(case, VAR, 1, B, 1)

@@ -74,7 +74,7 @@ struct ConvW { std::string wname, bname; int cin = 0, cout = 0, cout_pad = 0, nt
                bool nin = false; size_t w_off = 0, b_off = 0;
                int cin_src = 0, cout_src = 0;                 // extents of the host tensor when it is zero-padded to cin / cout
                size_t wb_off = 0; bool has_wb = false;        // slab-major copy for conv_v4_kernel (see pack_conv)
-               size_t wc_off = 0; bool has_wc = false;        // 16-channel-chunk copy for conv_v9_kernel (ConvArgs::wc)
+               size_t wc_off = 0; bool has_wc = false;        // 16-channel-chunk copy for conv_v10_kernel (ConvArgs::wc)
                bool split_in = false; };                      // wb = the bf16 hi / lo split copy of the input convolution (pack_conv_in_split)
 struct GNW { std::string prefix; int C = 0; size_t g_off = 0, b_off = 0; };
 struct ResW { int idx = 0, in_ch = 0, out_ch = 0; bool up = false, down = false, has_c2 = false;
@@ -929,10 +929,9 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
     if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
-    if (!strcmp(name, "conv_v9")) { conv_v9_set_enable((int)value); return USE_OK; }
-    if (!strcmp(name, "conv_v9_min_units")) { conv_v9_set_min_units((long)value); return USE_OK; }
     if (!strcmp(name, "conv_v10")) { conv_v10_set_enable((int)value); return USE_OK; }
     if (!strcmp(name, "conv_v10_min_units")) { conv_v10_set_min_units((long)value); return USE_OK; }
+    if (!strcmp(name, "conv_v10_max_units")) { conv_v10_set_max_units((long)value); return USE_OK; }
     if (!strcmp(name, "conv_v10_strip")) { conv_v10_set_strip((int)value); return USE_OK; }
     if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_mfma16")) { wgrad_set_mfma16((int)value); return USE_OK; }
@@ -1040,7 +1039,7 @@ int use_commit_weights(use_handle* h) {
 // ---- packed weight file: header + the device blob, so that a deployment starts without a state dict ------
 // The blob layout is private to a library build: BLOB_LAYOUT is bumped whenever pack_all / the blob offsets change.
 namespace {
-constexpr uint32_t BLOB_LAYOUT = 6;          // 6: + 16-channel-chunk copies (conv_v9); 5: + split-bf16 copy of the input convolution (16-bit modes); 4: piece-swizzled slab copies
+constexpr uint32_t BLOB_LAYOUT = 6;          // 6: + 16-channel-chunk copies (conv_v10); 5: + split-bf16 copy of the input convolution (16-bit modes); 4: piece-swizzled slab copies
 struct BlobHeader {
     char magic[8];                           // "USEHIPWB"
     uint32_t header_bytes, layout;
@@ -1647,7 +1646,6 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             case 7: if (!conv_sk_eligible(a)) return -1; launch_conv_sk(a, 0); return 0;
             case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
             case 4: if (!a.wb || (XC && !a.w2b) || a.H % 16 || a.W % 32) return -1; launch_conv_v4(a, 0); return 0;   // (conv_v4 has no partial tiles)
-            case 9: { conv_v9_set_enable(1); conv_v9_set_min_units(1); const bool ok = conv_v9_eligible(a); if (ok) launch_conv_v9(a, 0); conv_v9_set_enable(0); conv_v9_set_min_units(320); return ok ? 0 : -1; }
             case 10: { conv_v10_set_enable(1); conv_v10_set_min_units(1); const bool ok = conv_v10_eligible(a); if (ok) launch_conv_v10(a, 0); conv_v10_set_enable(0); conv_v10_set_min_units(320); return ok ? 0 : -1; }
             default: return -1;
         }

@@ -34,7 +34,7 @@ struct ConvArgs {
                             // (one (tap, chunk) slab contiguous: conv_v4), or null.  Rows are 64 bytes; the 16-byte
                             // piece q of row n is stored at position q ^ ((n >> 2) & 3) (bank-conflict-free LDS image for
                             // a lane-linear copy: conv_v4 stores it as it is)
-    const void* wc;         // optional 16-channel-chunk copy [(C0+C1)/16][ntaps][CoutPad][16] (conv_v9: one chunk's nine slabs of a
+    const void* wc;         // optional 16-channel-chunk copy [(C0+C1)/16][ntaps][CoutPad][16] (conv_v10: one chunk's nine slabs of a
                             // 128-channel block are nine contiguous 4 KB pieces - the image its LDS-DMA copies), 16-bit types only, or null
     int cout_pad;
     // optional second K segment: + conv1x1(concat(x0[XC0], x1[XC1])) with weights w2 [CoutPad][1][XC0+XC1]
@@ -72,15 +72,12 @@ void pyr_conv_set_pipe(int n);                          // pyramid-head convolut
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 128 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);
-// one-wave-per-SIMD persistent variant (use_conv_v9.hip, generated by gen_conv_v9.py): plain and residual 3x3 convolutions of the large maps
-bool conv_v9_eligible(const ConvArgs& a);
-void conv_v9_set_enable(int on);                         // default off
-void conv_v9_set_min_units(long n);                      // smallest launch (tiles x channel blocks x items) it is used for
-void launch_conv_v9(const ConvArgs& a, hipStream_t s);
-// two co-resident 4-wave workgroups per CU running conv_v9's generated MFMA stream, non-persistent (use_conv_v10.hip, gen_conv_v10.py)
+// two co-resident, non-persistent 4-wave workgroups per CU, one asm statement per MFMA (use_conv_v10.hip, generated by gen_conv_v10.py;
+// round 4's conv_v9 - one persistent wave per SIMD - was its first form: git history)
 bool conv_v10_eligible(const ConvArgs& a);
 void conv_v10_set_enable(int on);                        // default off
 void conv_v10_set_min_units(long n);
+void conv_v10_set_max_units(long n);
 void conv_v10_set_strip(int n);                          // tiles per workgroup
 void launch_conv_v10(const ConvArgs& a, hipStream_t s);
 // GroupNorm finalisation for the consumers that take a coefficient array (FIR resampling kernels): per-(b, group) mean / rstd
