@@ -21,6 +21,8 @@ import argparse
 import json
 import os
 import sys
+import shutil
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -110,6 +112,7 @@ def main():
                     help="BASELINE.json configs[] preset: 1 = 8 x 4 s, N=30 PC, bf16 (the default, the headline metric); 3 = batch 16, "
                          "N=200, corrector snr 0.5 (long-horizon latency config); 4 = 8 x 4 s per GPU, N=30 PC, fp16 storage (the "
                          "per-GPU workload of the 32-utterance / 4-GPU config)")
+    ap.add_argument("--no-power-probe", action="store_true", help="do not sample rocm-smi during the timed steps")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary sampler configurations (predictor-only, N=50, fp32)")
     ap.add_argument("--opt", action="append", default=[], help="use_set_option name=value (repeatable; same-box A/B of a tuning knob)")
     ap.add_argument("--roofline-only", action="store_true",
@@ -167,12 +170,41 @@ def main():
 
     for w in range(a.warmup):
         eng.sample(Y, seed=4321 + w)
+    # socket power / shader clock while the timed steps run (rank 0, a sampling thread calling rocm-smi: a separate process, nothing on
+    # the GPU's queues): DESIGN.md section 4 round 4 - the evaluation runs at the package's power limit, which is what bounds it
+    probe = {"W": [], "MHz": []}
+    stop_probe = threading.Event()
+
+    def power_thread():
+        import re
+        import subprocess
+        while not stop_probe.is_set():
+            try:
+                o = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+                m = re.search(r"Power \(W\): ([0-9.]+)", o)
+                c = re.search(r"sclk.*\((\d+)Mhz\)", o)
+                if m and c and float(m.group(1)) > 0:
+                    probe["W"].append(float(m.group(1))); probe["MHz"].append(float(c.group(1)))
+            except Exception:
+                return
+            stop_probe.wait(0.5)
+    pt = None
+    if rank == 0 and not a.no_power_probe and shutil.which("rocm-smi"):
+        pt = threading.Thread(target=power_thread, daemon=True); pt.start()
     barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
         out = eng.sample(Y, seed=4321 + a.warmup + k)
     barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+    stop_probe.set()
+    if pt is not None:
+        pt.join(timeout=6)
+    # (the first samples fall into the ramp: keep those within 10 % of the maximum)
+    keep = [i for i, w_ in enumerate(probe["W"]) if w_ >= 0.9 * max(probe["W"])] if probe["W"] else []
+    power_probe = ({"socket_W": round(sum(probe["W"][i] for i in keep) / len(keep), 1), "sclk_MHz": round(sum(probe["MHz"][i] for i in keep) / len(keep)),
+                    "samples": len(keep), "source": "rocm-smi --showpower --showclocks every 0.5 s during the timed steps (samples within 10 % of the maximum)"}
+                   if keep else None)
     if a.steps:
         assert torch.isfinite(torch.view_as_real(out)).all(), "non-finite sampler output"
     else:
@@ -306,6 +338,8 @@ def main():
             "padded_frame_nfe_per_s": round(padded_frame_nfe_per_s, 1),
             "roofline": roofline,
         }
+        if power_probe is not None:
+            res["power_probe"] = power_probe
         if secondary is not None:
             res["secondary"] = secondary
         if world == 1 and not a.no_cpu_baseline:
