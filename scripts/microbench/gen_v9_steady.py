@@ -102,6 +102,8 @@ out = f'''// GENERATED by gen_v9_steady.py - do not edit.  hipcc --offload-arch=
 #include <vector>
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #define WPE {WPEV}
+#define GRID {512 if TWO else 256}
+#define LDS_BYTES {LDS}
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) char lds_char;
@@ -178,7 +180,7 @@ template <int MODE> static void run(const char* what, const void* gx, const void
            (double)h[0] / nwin, (double)h[0] / (best * 1e6));
 }
 
-int main() {
+int main(int argc, char** argv) {
     const size_t xb = (size_t)4 * 512 * 640 * 128 * 2, wb = (size_t)1 << 24;
     void *gx, *gw; float* sink; unsigned long long* cyc;
     hipMalloc(&gx, xb); hipMalloc(&gw, wb); hipMalloc(&sink, 256 * 256 * 4); hipMalloc(&cyc, 64);
@@ -190,6 +192,23 @@ int main() {
     }
     hipMemcpy(gx, h.data(), xb, hipMemcpyHostToDevice); hipMemcpy(gw, h.data(), wb, hipMemcpyHostToDevice);
     const int nwin = 8 * 10 * 8;                                       // 80 tiles of 8 chunks per workgroup
+    if (argc > 2) {                                                    // soak: one mode back to back for argv[2] seconds (power / clock sampling from outside)
+        const int mode = atoi(argv[1]); const double secs = atof(argv[2]);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        double total_ms = 0.0; long launches = 0;
+        while (total_ms < secs * 1e3) {
+            hipEventRecord(e0);
+            for (int l = 0; l < 50; ++l) {
+#define SOAK(M) case M: hipFuncSetAttribute(reinterpret_cast<const void*>(&v9_steady<M>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); hipLaunchKernelGGL(v9_steady<M>, dim3(GRID), dim3(256), LDS_BYTES, 0, gx, gw, sink, cyc, nwin, (unsigned)xb, (unsigned)wb); break;
+                switch (mode) { SOAK(31) SOAK(0) SOAK(8) SOAK(23) default: return 2; }
+            }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); total_ms += ms; launches += 50;
+        }
+        printf("mode %d: %ld launches in %.1f s -> %.1f TFLOP/s sustained\\n", mode, launches, total_ms * 1e-3,
+               (double)GRID * 4 * (double)nwin * 72 * 32768.0 * launches / (total_ms * 1e-3) * 1e-12);
+        return 0;
+    }
     run<31>("MFMAs only", gx, gw, sink, cyc, nwin, (unsigned)xb, (unsigned)wb);
     run<30>("+ fragment reads", gx, gw, sink, cyc, nwin, (unsigned)xb, (unsigned)wb);
     run<14>("+ fragment reads + barrier", gx, gw, sink, cyc, nwin, (unsigned)xb, (unsigned)wb);

@@ -933,6 +933,7 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "conv_v10_min_units")) { conv_v10_set_min_units((long)value); return USE_OK; }
     if (!strcmp(name, "conv_v10_max_units")) { conv_v10_set_max_units((long)value); return USE_OK; }
     if (!strcmp(name, "conv_v10_strip")) { conv_v10_set_strip((int)value); return USE_OK; }
+    if (!strcmp(name, "conv_v10_stagger")) { conv_v10_set_stagger((int)value); return USE_OK; }
     if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_mfma16")) { wgrad_set_mfma16((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_blocks")) { wgrad_set_blocks((int)value); return USE_OK; }

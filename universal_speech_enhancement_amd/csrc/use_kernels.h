@@ -79,6 +79,7 @@ void conv_v10_set_enable(int on);                        // default off
 void conv_v10_set_min_units(long n);
 void conv_v10_set_max_units(long n);
 void conv_v10_set_strip(int n);                          // tiles per workgroup
+void conv_v10_set_stagger(int n);                        // start offset of the second resident workgroups (x 8 k cycles)
 void launch_conv_v10(const ConvArgs& a, hipStream_t s);
 // GroupNorm finalisation for the consumers that take a coefficient array (FIR resampling kernels): per-(b, group) mean / rstd
 // from the per-channel totals of up to two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b): y = a*x + b.
