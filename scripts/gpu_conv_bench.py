@@ -1,7 +1,7 @@
-"""Single-convolution A/B harness on the GPU box (use_conv_bench): times conv_v2 / conv_v4 / conv_v5 on the layer shapes of the
+"""Single-convolution A/B harness on the GPU box (use_conv_bench): times conv_v2 (2) / conv_v4 (4) / conv_v10 (10) / conv_sk (7) / the generic kernel (1) on the layer shapes of the
 NCSN++ Large score network at the configs[1] sub-batch (B=4) and checks that the variants agree.
 
-    python scripts/gpu_conv_bench.py [--variants 4,5] [--iters 10] [--cases main|all] [--opt name=value ...]
+    python scripts/gpu_conv_bench.py [--variants 4,10] [--iters 10] [--cases main|all] [--opt name=value ...]
 """
 import argparse
 import ctypes as C
@@ -64,7 +64,7 @@ def run(case, variant, iters, B, dtype, want_out=True):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="4,5")
+    ap.add_argument("--variants", default="4,10")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cases", default="main")
     ap.add_argument("--batch", type=int, default=4)
