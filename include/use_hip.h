@@ -125,6 +125,13 @@ int use_sde_predictor(use_handle* h, int predictor, float t, int N, const void* 
 int use_sde_corrector(use_handle* h, int corrector, float t, float snr, int B, const void* x, const void* score,
                       const void* noise, uint64_t seed, void* x_out, void* x_mean, int64_t n, use_stream_t s);
 
+/* The device noise stream of use_sample(noise = NULL, seed), draw by draw: out[i] (complex64, n elements = the whole batch tensor
+ * [B,1,F,T']) = the z that draw `draw` uses at element i -- draw 0 is the prior's randn_like (sdes.py:254), then per reverse step the
+ * corrector draws (sampling/correctors.py:54) followed by the predictor draw (sampling/predictors.py:63), the reference's order of
+ * consumption.  use_sample(noise = [use_fill_noise(seed, d) for d in 0..use_num_noise_draws-1]) is bit-identical to
+ * use_sample(noise = NULL, seed): this is how the timed (device-noise) branch is pinned to the oracle in tests/. */
+int use_fill_noise(use_handle* h, uint64_t seed, int draw, void* out, int64_t n, use_stream_t s);
+
 /* Raw backbone output NCSNpp.forward(cat[x, y], t) (ncsnpp.py:324-501), i.e. without the sign flip of use_score.
  * x, y: complex64 [B,1,F,T'] device; y must be null when input_channels == 2 (the input is x alone), t must be null when
  * the handle is unconditional and may be null when it is conditional only if no_sigma_scale... (not supported: give t). */

@@ -1,7 +1,7 @@
-"""Single-convolution A/B harness on the GPU box (use_conv_bench): times conv_v2 (2) / conv_v4 (4) / conv_v10 (10) / conv_sk (7) / the generic kernel (1) on the layer shapes of the
+"""Single-convolution A/B harness on the GPU box (use_conv_bench): times conv_v2 (2) / conv_v4 (4) / conv_sk (7) / the generic kernel (1) on the layer shapes of the
 NCSN++ Large score network at the configs[1] sub-batch (B=4) and checks that the variants agree.
 
-    python scripts/gpu_conv_bench.py [--variants 4,10] [--iters 10] [--cases main|all] [--opt name=value ...]
+    python scripts/gpu_conv_bench.py [--variants 4,2] [--iters 10] [--cases main|all] [--opt name=value ...]
 """
 import argparse
 import ctypes as C

@@ -1,5 +1,5 @@
 """40 score evaluations of the configs[1] shape (two sub-batch streams) must be bit-identical (integer-atomic GroupNorm totals, fixed
-summation orders, no race in the LDS-DMA pipelines): USE_HIP_OPTS=conv_v10=1 python scripts/stress_determinism.py"""
+summation orders): python scripts/stress_determinism.py"""
 import os, sys, zlib
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch

@@ -888,35 +888,6 @@ def test_conv_sk_matches_the_generic_kernel(dtype, tol):
         assert np.abs(sk[1] - ref[1]).max() <= 1e-3 * np.abs(ref[1]).max()
 
 
-@pytest.mark.parametrize("dtype", [1, 2])
-def test_conv_v10_matches_the_generic_kernel(dtype):
-    """conv_v10_kernel (two co-resident 4-wave workgroups per CU, strips of tiles, AGPR accumulators, generated schedule: gen_conv_v10.py;
-    off by default) against conv_kernel on the same seeded operands through the single-convolution harness: one tile, tile borders in
-    both directions, a residual, concatenated inputs (chunks from two tensors), two 128-channel output blocks, several items, strips
-    of one and of several tiles, with and without the activation.  Tolerance = 4 ulps of the storage type relative to the
-    largest output (the 16-channel chunks give a different summation order); GroupNorm totals to 1e-3."""
-    import ctypes as C
-    from universal_speech_enhancement_amd import _lib
-    from universal_speech_enhancement_amd._lib import UseConvCase
-    tol = lp.op_bound(dtype)
-    # (B, H, W, C0, C1, Cout, XC0, XC1, act, gn, temb, res)
-    cases = [(1, 8, 32, 128, 0, 128, 0, 0, 1, 1, 1, 0), (2, 16, 64, 128, 0, 128, 0, 0, 1, 1, 1, 0), (3, 32, 96, 128, 0, 128, 0, 0, 1, 1, 0, 1),
-             (2, 16, 64, 256, 128, 128, 0, 0, 1, 1, 1, 0), (2, 16, 64, 256, 0, 256, 0, 0, 0, 1, 1, 0), (4, 64, 160, 128, 0, 128, 0, 0, 1, 1, 1, 1), (4, 256, 640, 128, 0, 128, 0, 0, 1, 1, 1, 1)]
-    for (B, H, W, C0, C1, Cout, XC0, XC1, act, gn, temb, res) in cases:
-        got = {}
-        for variant in (1, 10):
-            c = UseConvCase(B, H, W, C0, C1, Cout, XC0, XC1, act, gn, temb, res, 1, dtype, variant, 1)
-            out = np.empty((B, H, W, Cout), np.float32); st = np.empty((B, Cout, 2), np.float32)
-            ms, fl = C.c_double(), C.c_double()
-            rc = _lib.lib().use_conv_bench(C.byref(c), out.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), C.byref(ms), C.byref(fl))
-            assert rc == 0, (variant, _lib.lib().use_last_error())
-            got[variant] = (out, st)
-        ref, v10 = got[1], got[10]
-        assert np.isfinite(v10[0]).all()
-        assert np.abs(v10[0] - ref[0]).max() <= tol * np.abs(ref[0]).max(), (B, H, W, C0, C1, Cout, res)
-        assert np.abs(v10[1] - ref[1]).max() <= 1e-3 * np.abs(ref[1]).max()
-
-
 def test_plans_and_graphs_of_recent_shapes_are_kept(engines):
     """A predict run over files of a few distinct lengths: 20 batches cycling through 5 padded lengths build 5 plans and capture 5
     graphs, not 20 (the plans of the most recently used shapes are parked with their graphs, use_engine.cpp: plan cache), and a

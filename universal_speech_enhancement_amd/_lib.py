@@ -78,6 +78,7 @@ SYMBOLS = {
     "use_stft_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, C.c_float, C.c_float, _vp]),
     "use_istft_back": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, C.c_float, C.c_float, _vp]),
     "use_sde_prior": (_i, [_vp, _vp, _vp, _u64, _vp, _i64, _vp]),
+    "use_fill_noise": (_i, [_vp, _u64, _i, _vp, _i64, _vp]),
     "use_sde_predictor": (_i, [_vp, _i, _f, _i, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _i64, _vp]),
     "use_sde_corrector": (_i, [_vp, _i, _f, _f, _i, _vp, _vp, _vp, _u64, _vp, _vp, _i64, _vp]),
     "use_debug_tensor": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)]),
@@ -124,12 +125,19 @@ def lib() -> C.CDLL:
                 continue               # an older build under A/B test may lack the newest entry points
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        _lib = L
-        # USE_HIP_OPTS="name=value,...": use_set_option calls at load time (A/B runs of the test suite and the bench with an option flipped)
+        # USE_HIP_OPTS="name=value,...": use_set_option calls at load time (A/B runs of the test suite and the bench with an option flipped);
+        # applied BEFORE the library is published: a bad entry fails every lib() call, not only the first
         for kv in filter(None, os.environ.get("USE_HIP_OPTS", "").split(",")):
-            k, v = kv.split("=")
-            if L.use_set_option(k.encode(), int(v)) < 0:
+            k, sep, v = kv.partition("=")
+            if not sep or not k.strip():
+                raise UseHipError(f"USE_HIP_OPTS: entry {kv!r} is not name=value")
+            try:
+                iv = int(v)
+            except ValueError:
+                raise UseHipError(f"USE_HIP_OPTS: {kv!r}: the value must be an integer") from None
+            if L.use_set_option(k.strip().encode(), iv) < 0:
                 raise UseHipError(f"USE_HIP_OPTS: {kv}: " + L.use_last_error().decode(errors="replace"))
+        _lib = L
     return _lib
 
 

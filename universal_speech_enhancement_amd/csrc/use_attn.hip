@@ -213,11 +213,10 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(AttnArgs p) {
 bool attn_fused_eligible(int dtype, int N, int C) { return dtype != DT_F32 && C == AT_C && N >= 1 && N <= AT_NMAX; }
 
 void launch_attn_fused(const AttnArgs& a, int dtype, int B, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LdsAttrOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, AT_SMEM);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, AT_SMEM);
-        attr_set = true;
     }
     if (dtype == DT_BF16) hipLaunchKernelGGL(attn_fused_kernel<__bf16>, dim3(B), dim3(512), AT_SMEM, s, a);
     else                  hipLaunchKernelGGL(attn_fused_kernel<_Float16>, dim3(B), dim3(512), AT_SMEM, s, a);

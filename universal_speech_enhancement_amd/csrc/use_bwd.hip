@@ -857,11 +857,10 @@ size_t wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin, int ntaps,
 template <typename T>
 static void wgrad_tile_t(const void* dy, const void* x, float* part, float* bpart, int B, int H, int W, int Cout, int Cin, int ntaps, const WgradPlan& q,
                          hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static LdsAttrOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel<9, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel<1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
-        attr = true;
     }
     const dim3 grid(q.tiles * q.nslices);
     if (ntaps == 9) hipLaunchKernelGGL((wgrad_tile_kernel<9, T>), grid, dim3(256), WG_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
@@ -870,11 +869,10 @@ static void wgrad_tile_t(const void* dy, const void* x, float* part, float* bpar
 template <typename T>
 static void wgrad16_t(const void* dy, const void* x, float* part, float* bpart, int B, int H, int W, int Cout, int Cin, int ntaps, const WgradPlan& q,
                       hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static LdsAttrOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel<9, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WH_SMEM);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel<1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WH_SMEM);
-        attr = true;
     }
     const dim3 grid(q.tiles * q.nslices);
     if (ntaps == 9) hipLaunchKernelGGL((wgrad16_kernel<9, T>), grid, dim3(256), WH_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);

@@ -494,12 +494,9 @@ static void v2_launch_t(const ConvArgs& a, hipStream_t s) {
     constexpr int MAIN = 2 * V2_HE * HPITCH + 2 * V2_BN * ROWB + 512 * 16 + 1024 * 8;
     constexpr int EPI = 8 * 32 * (64 + 4) * 4 + 4 * V2_BN * 2 * 4;
     constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
-    static bool attr_set = false;
+    static LdsAttrOnce attr;                                 // per (instantiation, device)
     auto kern = conv_v2_kernel<TIN, TOUT, CK, ACT>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        attr_set = true;
-    }
+    attr(kern, SMEM);
     dim3 grid(conv_v2_tiles(a.H, a.W), (a.Cout + V2_BN - 1) / V2_BN, a.B);
     hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, s, a);
 }

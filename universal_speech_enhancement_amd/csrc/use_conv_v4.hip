@@ -596,12 +596,9 @@ static void v4_launch_t(const ConvArgs& a, hipStream_t s) {
     constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
 #endif
     static_assert(MAIN <= 152064 && EPI <= 152064 && SMEM <= 163840, "LDS budget");
-    static bool attr_set = false;
+    static LdsAttrOnce attr;                                 // per (instantiation, device)
     auto kern = conv_v4_kernel<TIN, TOUT, CK, ACT>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        attr_set = true;
-    }
+    attr(kern, SMEM);
     dim3 grid(conv_v4_tiles(a.H, a.W), (a.Cout + V4_BN - 1) / V4_BN, a.B);
     hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, s, a);
 }

@@ -74,7 +74,6 @@ struct ConvW { std::string wname, bname; int cin = 0, cout = 0, cout_pad = 0, nt
                bool nin = false; size_t w_off = 0, b_off = 0;
                int cin_src = 0, cout_src = 0;                 // extents of the host tensor when it is zero-padded to cin / cout
                size_t wb_off = 0; bool has_wb = false;        // slab-major copy for conv_v4_kernel (see pack_conv)
-               size_t wc_off = 0; bool has_wc = false;        // 16-channel-chunk copy for conv_v10_kernel (ConvArgs::wc)
                bool split_in = false; };                      // wb = the bf16 hi / lo split copy of the input convolution (pack_conv_in_split)
 struct GNW { std::string prefix; int C = 0; size_t g_off = 0, b_off = 0; };
 struct ResW { int idx = 0, in_ch = 0, out_ch = 0; bool up = false, down = false, has_c2 = false;
@@ -291,8 +290,6 @@ static int build_arch(use_handle* h) {
         // 3x3 convolutions and the res-block shortcuts fused into them get a second, slab-major copy
         w.has_wb = !w.nin && w.cout_pad % 128 == 0 && w.cin % conv_v4_chunk(w.w_dtype) == 0 && (w.ntaps == 9 || w.ntaps == 1);
         if (w.has_wb) w.wb_off = take((size_t)w.ntaps * w.cout_pad * w.cin * dtype_size(w.w_dtype));
-        w.has_wc = !w.nin && w.ntaps == 9 && w.w_dtype != DT_F32 && w.cout_pad % 128 == 0 && w.cin % 32 == 0 && w.cin >= 128;
-        if (w.has_wc) w.wc_off = take((size_t)w.ntaps * w.cout_pad * w.cin * dtype_size(w.w_dtype));
     };
     // the input convolution in the 16-bit modes: split-bf16 copy [cout_pad][CONV_IN_SPLIT_K] for conv_in_split_kernel
     auto lay_conv_in = [&](ConvW& w) {
@@ -325,7 +322,7 @@ static int build_arch(use_handle* h) {
 // ---------------------------------------------------------------------------------------------------------
 // host float weights -> device layouts: dst [cout_pad][tap][cin] (see use_kernels.h) and, when dstb != null, the slab-major
 // copy [tap][chunk][cout_pad][ck] with piece-swizzled 64-byte rows (ConvArgs::wb)
-static void pack_conv_raw(const float* src, const ConvW& w, char* dst, char* dstb, char* dstc = nullptr) {
+static void pack_conv_raw(const float* src, const ConvW& w, char* dst, char* dstb) {
     const size_t es = dtype_size(w.w_dtype);
     auto put = [&](char* base, size_t o, float v) {
         if (w.w_dtype == DT_F32) ((float*)base)[o] = v;
@@ -350,13 +347,6 @@ static void pack_conv_raw(const float* src, const ConvW& w, char* dst, char* dst
                     put(dstb, (((size_t)tap * nchunks + ci / ck) * w.cout_pad + co) * ck + (((e / vec) ^ ((co >> 2) & 3)) * vec + e % vec), v);
                 }
     }
-    if (dstc) {                                               // [chunk of 16][tap][cout_pad][16] (ConvArgs::wc)
-        memset(dstc, 0, (size_t)w.ntaps * w.cout_pad * w.cin * es);
-        for (int tap = 0; tap < w.ntaps; ++tap)
-            for (int co = 0; co < w.cout_src; ++co)
-                for (int ci = 0; ci < w.cin_src; ++ci)
-                    put(dstc, (((size_t)(ci / 16) * w.ntaps + tap) * w.cout_pad + co) * 16 + ci % 16, src[((size_t)co * w.cin_src + ci) * w.ntaps + tap]);
-    }
 }
 // Input convolution, 16-bit modes: w = wh + wl with wh = bf16(w), wl = bf16(w - wh); row n of the copy holds the K = 112 operand
 // of conv_in_split_kernel: k = 4 u + ci, unit u = (block, tap): block 0 -> wh (meets xh), block 1 -> wl (meets xh), block 2 -> wh
@@ -377,7 +367,7 @@ static void pack_conv_in_split(const float* src, const ConvW& w, char* dst) {
 }
 static void pack_conv(const use_handle* h, const ConvW& w, char* blob) {
     const std::vector<float>& bias = h->host_w.at(w.bname);
-    pack_conv_raw(h->host_w.at(w.wname).data(), w, blob + w.w_off, (w.has_wb && !w.split_in) ? blob + w.wb_off : nullptr, w.has_wc ? blob + w.wc_off : nullptr);
+    pack_conv_raw(h->host_w.at(w.wname).data(), w, blob + w.w_off, (w.has_wb && !w.split_in) ? blob + w.wb_off : nullptr);
     if (w.split_in) pack_conv_in_split(h->host_w.at(w.wname).data(), w, blob + w.wb_off);
     memset(blob + w.b_off, 0, (size_t)w.cout * 4);
     memcpy(blob + w.b_off, bias.data(), (size_t)w.cout_src * 4);
@@ -508,7 +498,6 @@ struct Fwd {
             p.gn_inv_n = 1.0f / ((float)(C / groups) * (float)(a.H * a.W)); p.gn_eps = 1e-6f;
         }
         p.wb = w.has_wb ? h->blob + w.wb_off : nullptr;
-        p.wc = w.has_wc ? h->blob + w.wc_off : nullptr;
         p.bias = W<float>(w2 ? bias_off : w.b_off);
         if (w2) { p.x0 = sx0->p; p.XC0 = sx0->C; p.x1 = sx1 ? sx1->p : nullptr; p.XC1 = sx1 ? sx1->C : 0; p.w2 = h->blob + w2->w_off;
                   p.w2b = w2->has_wb ? h->blob + w2->wb_off : nullptr; }
@@ -929,11 +918,6 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
     if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
-    if (!strcmp(name, "conv_v10")) { conv_v10_set_enable((int)value); return USE_OK; }
-    if (!strcmp(name, "conv_v10_min_units")) { conv_v10_set_min_units((long)value); return USE_OK; }
-    if (!strcmp(name, "conv_v10_max_units")) { conv_v10_set_max_units((long)value); return USE_OK; }
-    if (!strcmp(name, "conv_v10_strip")) { conv_v10_set_strip((int)value); return USE_OK; }
-    if (!strcmp(name, "conv_v10_stagger")) { conv_v10_set_stagger((int)value); return USE_OK; }
     if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_mfma16")) { wgrad_set_mfma16((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_blocks")) { wgrad_set_blocks((int)value); return USE_OK; }
@@ -1040,7 +1024,7 @@ int use_commit_weights(use_handle* h) {
 // ---- packed weight file: header + the device blob, so that a deployment starts without a state dict ------
 // The blob layout is private to a library build: BLOB_LAYOUT is bumped whenever pack_all / the blob offsets change.
 namespace {
-constexpr uint32_t BLOB_LAYOUT = 6;          // 6: + 16-channel-chunk copies (conv_v10); 5: + split-bf16 copy of the input convolution (16-bit modes); 4: piece-swizzled slab copies
+constexpr uint32_t BLOB_LAYOUT = 7;          // 7: the 16-channel-chunk copies of round 4 (conv_v10, removed) are gone again; 5: + split-bf16 copy of the input convolution (16-bit modes); 4: piece-swizzled slab copies
 struct BlobHeader {
     char magic[8];                           // "USEHIPWB"
     uint32_t header_bytes, layout;
@@ -1525,6 +1509,16 @@ int use_sde_prior(use_handle* h, const void* y, const void* noise, uint64_t seed
     return USE_OK;
 }
 
+int use_fill_noise(use_handle* h, uint64_t seed, int draw, void* out, int64_t n, use_stream_t s) {
+    // draw `draw` of the device noise stream of use_sample(noise = NULL, seed): element i = Philox4x32-10(key = seed, counter = (i, draw))
+    int rc = ensure_sde_scratch(h); if (rc) return rc;
+    if (!out || n < 1 || draw < 0) return fail(USE_E_INVALID, "bad arguments");
+    hipLaunchKernelGGL(set_rng_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, h->sde_rng, (unsigned long long)seed, 0ull);
+    launch_fill_noise((float2*)out, RngRef{h->sde_rng, (unsigned)draw}, (long)n, (hipStream_t)s);
+    HIPCHK(hipGetLastError());
+    return USE_OK;
+}
+
 int use_sde_predictor(use_handle* h, int predictor, float t, int N, const void* x, const void* y, const void* score,
                       const void* noise, uint64_t seed, void* x_out, void* x_mean, int64_t n, use_stream_t s) {
     int rc = ensure_sde_scratch(h); if (rc) return rc;
@@ -1604,7 +1598,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
     float* coef = c->gn ? (float*)dalloc((size_t)c->B * Cin * 2 * 4) : nullptr;
     float* bias = (float*)dalloc((size_t)c->Cout * 4); float* temb = (float*)dalloc((size_t)c->B * c->Cout * 4);
     const size_t wbytes = (size_t)9 * w.cout_pad * Cin * es, w2bytes = (size_t)w2.cout_pad * std::max(XC, 1) * es;
-    char* dw = (char*)dalloc(wbytes); char* dwb = (char*)dalloc(wbytes); char* dwc = (char*)dalloc(wbytes);
+    char* dw = (char*)dalloc(wbytes); char* dwb = (char*)dalloc(wbytes);
     char* dw2 = XC ? (char*)dalloc(w2bytes) : nullptr; char* dw2b = XC ? (char*)dalloc(w2bytes) : nullptr;
     const size_t stats_bytes = (size_t)c->B * c->Cout * 2 * sizeof(long long);
     long long* stats = c->stats ? (long long*)dalloc(stats_bytes) : nullptr;
@@ -1621,14 +1615,12 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
         const float sc = 1.0f / std::sqrt((float)Cin * 9.f / 3.f);
         for (auto& v : hw) v = rnd() * sc;
         for (auto& v : hw2) v = rnd() * (1.0f / std::sqrt((float)std::max(XC, 1) / 3.f));
-        std::vector<char> hp(wbytes), hpb(wbytes), hpc(wbytes);
+        std::vector<char> hp(wbytes), hpb(wbytes);
         const bool slab = w.cout_pad % 128 == 0 && Cin % conv_v4_chunk(dt) == 0;
-        const bool c16 = dwc && dt != DT_F32 && w.cout_pad % 128 == 0 && Cin % 32 == 0;
-        pack_conv_raw(hw.data(), w, hp.data(), slab ? hpb.data() : nullptr, c16 ? hpc.data() : nullptr);
+        pack_conv_raw(hw.data(), w, hp.data(), slab ? hpb.data() : nullptr);
         (void)hipMemcpy(dw, hp.data(), wbytes, hipMemcpyHostToDevice);
         if (slab) (void)hipMemcpy(dwb, hpb.data(), wbytes, hipMemcpyHostToDevice);
-        if (c16) (void)hipMemcpy(dwc, hpc.data(), wbytes, hipMemcpyHostToDevice);
-        a.w = dw; a.wb = slab ? dwb : nullptr; a.wc = c16 ? dwc : nullptr;
+        a.w = dw; a.wb = slab ? dwb : nullptr;
         if (XC) {
             std::vector<char> hq(w2bytes), hqb(w2bytes);
             const bool slab2 = XC % conv_v4_chunk(dt) == 0 && w2.cout_pad % 128 == 0;
@@ -1647,7 +1639,6 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             case 7: if (!conv_sk_eligible(a)) return -1; launch_conv_sk(a, 0); return 0;
             case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
             case 4: if (!a.wb || (XC && !a.w2b) || a.H % 16 || a.W % 32) return -1; launch_conv_v4(a, 0); return 0;   // (conv_v4 has no partial tiles)
-            case 10: { conv_v10_set_enable(1); conv_v10_set_min_units(1); const bool ok = conv_v10_eligible(a); if (ok) launch_conv_v10(a, 0); conv_v10_set_enable(0); conv_v10_set_min_units(320); return ok ? 0 : -1; }
             default: return -1;
         }
     };

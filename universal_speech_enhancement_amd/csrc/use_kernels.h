@@ -6,6 +6,25 @@
 
 namespace use {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of (kernel, DEVICE): one flag per device, not per process - a second
+// handle on another device of the same process (use_create(cfg, device, ...)) would otherwise launch its > 64 KB-LDS kernels unprepared
+constexpr int USE_MAX_DEVICES = 64;
+struct LdsAttrOnce {
+    bool done[USE_MAX_DEVICES] = {};
+    template <typename K> void operator()(K kern, int bytes) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= USE_MAX_DEVICES) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); return; }
+        if (!done[d]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); done[d] = true; }
+    }
+    bool first() {            // several kernels behind one flag: true once per device
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= USE_MAX_DEVICES) return true;
+        if (done[d]) return false;
+        done[d] = true; return true;
+    }
+};
+
+
 enum DType { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 
@@ -34,8 +53,6 @@ struct ConvArgs {
                             // (one (tap, chunk) slab contiguous: conv_v4), or null.  Rows are 64 bytes; the 16-byte
                             // piece q of row n is stored at position q ^ ((n >> 2) & 3) (bank-conflict-free LDS image for
                             // a lane-linear copy: conv_v4 stores it as it is)
-    const void* wc;         // optional 16-channel-chunk copy [(C0+C1)/16][ntaps][CoutPad][16] (conv_v10: one chunk's nine slabs of a
-                            // 128-channel block are nine contiguous 4 KB pieces - the image its LDS-DMA copies), 16-bit types only, or null
     int cout_pad;
     // optional second K segment: + conv1x1(concat(x0[XC0], x1[XC1])) with weights w2 [CoutPad][1][XC0+XC1]
     // (the res-block shortcut Conv_2 fused into Conv_1; raw input, no affine / activation)
@@ -70,17 +87,8 @@ void launch_conv_sk(const ConvArgs& a, hipStream_t s);
 void launch_conv_generic(const ConvArgs& a, hipStream_t s);   // conv_kernel / pyr_conv_kernel / conv_in_kernel only (no specialised schedule)
 void pyr_conv_set_pipe(int n);                          // pyramid-head convolution: workgroups per item of the pipelined form (0: off)
 bool conv_v4_eligible(const ConvArgs& a);
-void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 128 workgroups per image)
+void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 80 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);
-// two co-resident, non-persistent 4-wave workgroups per CU, one asm statement per MFMA (use_conv_v10.hip, generated by gen_conv_v10.py;
-// round 4's conv_v9 - one persistent wave per SIMD - was its first form: git history)
-bool conv_v10_eligible(const ConvArgs& a);
-void conv_v10_set_enable(int on);                        // default off
-void conv_v10_set_min_units(long n);
-void conv_v10_set_max_units(long n);
-void conv_v10_set_strip(int n);                          // tiles per workgroup
-void conv_v10_set_stagger(int n);                        // start offset of the second resident workgroups (x 8 k cycles)
-void launch_conv_v10(const ConvArgs& a, hipStream_t s);
 // GroupNorm finalisation for the consumers that take a coefficient array (FIR resampling kernels): per-(b, group) mean / rstd
 // from the per-channel totals of up to two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b): y = a*x + b.
 void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta,

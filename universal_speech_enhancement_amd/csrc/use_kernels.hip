@@ -893,7 +893,6 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     }
 #endif
     if (conv_sk_eligible(a)) { launch_conv_sk(a, s); return; }
-    if (conv_v10_eligible(a)) { launch_conv_v10(a, s); return; }
     if (conv_v4_eligible(a)) { launch_conv_v4(a, s); return; }
     if (conv_v2_eligible(a)) { launch_conv_v2(a, s); return; }
     launch_conv_generic(a, s);
@@ -903,21 +902,19 @@ static int g_pyr_pipe = 128;      // workgroups per item of pyr_conv_pipe_kernel
 void pyr_conv_set_pipe(int n) { g_pyr_pipe = n; }
 void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
     if (pyr_conv_eligible(a)) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static LdsAttrOnce attr_set;
+        if (attr_set.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, PYR_SMEM);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, PYR_SMEM);
-            attr_set = true;
         }
         const int ntiles = tiles_per_image(a.H, a.W);
         if (a.C0 <= 2 * PYR_CB && g_pyr_pipe) {              // pipelined form: <= 2 workgroups per CU worth of workgroups per item, several tiles each
-            static bool attr2 = false;
-            if (!attr2) {
+            static LdsAttrOnce attr2;
+            if (attr2.first()) {
 #define USE_PYRP_ATTR(T, O, A) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_pipe_kernel<T, O, A>), hipFuncAttributeMaxDynamicSharedMemorySize, PYRP_SMEM);
                 USE_PYRP_ATTR(__bf16, true, true) USE_PYRP_ATTR(__bf16, true, false) USE_PYRP_ATTR(__bf16, false, true) USE_PYRP_ATTR(__bf16, false, false)
                 USE_PYRP_ATTR(_Float16, true, true) USE_PYRP_ATTR(_Float16, true, false) USE_PYRP_ATTR(_Float16, false, true) USE_PYRP_ATTR(_Float16, false, false)
 #undef USE_PYRP_ATTR
-                attr2 = true;
             }
             const int tpw = (ntiles + g_pyr_pipe - 1) / g_pyr_pipe;
             const dim3 grid((ntiles + tpw - 1) / tpw, 1, a.B);
@@ -1439,8 +1436,8 @@ void launch_istft_back(const float2* X, const float* win, const float2* tw, floa
     const int F = N / 2 + 1, nfr = (N + hop - 1) / hop;
     const int nblocks = (L + N / 2 + hop - 1) / hop;          // blocks of centre-padded samples that reach an output sample
     const size_t sh = (size_t)N * 8 + (size_t)nfr * F * 8;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(istft_back_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; }
+    static LdsAttrOnce attr;
+    attr(istft_back_kernel, 64 * 1024);
     hipLaunchKernelGGL(istft_back_kernel, dim3(nblocks, B), dim3(256), sh, s, X, win, tw, wav, L, N, hop, Tpad, F, nfr, 1.f / factor,
                        1.f / expo);
 }

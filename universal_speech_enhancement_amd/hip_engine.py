@@ -309,6 +309,14 @@ class HipScoreEngine:
                                       _stream_ptr(y.device)), "use_sample_cond2")
         return out
 
+    def fill_noise(self, seed: int, draw: int, shape) -> torch.Tensor:
+        """Draw ``draw`` of the device noise stream of ``sample(noise=None, seed=seed)`` as a complex64 tensor of ``shape`` = the whole
+        batch tensor [B,1,F,T'] (``use_fill_noise``): draw 0 is the prior's, then per reverse step the corrector draws and the
+        predictor draw.  Replaying these through ``sample(noise=...)`` reproduces the device-noise run bit for bit."""
+        out = torch.empty(tuple(shape), dtype=torch.complex64, device=f"cuda:{self.device}")
+        check(self.L.use_fill_noise(self.h, int(seed) & (2**64 - 1), int(draw), out.data_ptr(), out.numel(), _stream_ptr(out.device)), "use_fill_noise")
+        return out
+
     def debug_tensor(self, name: str) -> torch.Tensor:
         """Copy of a named intermediate of the last score evaluation as float32 [B,H,W,C]."""
         p, dims, dt = C.c_void_p(), (C.c_int * 4)(), C.c_int()
