@@ -21,7 +21,6 @@ import argparse
 import json
 import os
 import sys
-import shutil
 import threading
 import time
 
@@ -94,6 +93,55 @@ def cpu_baseline(sd_np):
                       f"NFE to the metric's 60-NFE sampler"}
 
 
+def pci_bus_id(device_index):
+    """hipDeviceGetPCIBusId of a device (what tells two ranks on one GPU from two GPUs), through the HIP runtime torch has loaded."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0:
+            return buf.value.decode()
+    except OSError:
+        pass
+    p = torch.cuda.get_device_properties(device_index)
+    return str(getattr(p, "pci_bus_id", getattr(p, "uuid", f"cuda:{device_index}")))
+
+
+def train_step_bench(dev, steps=3):
+    """One optimisation step (train_step forward + backward + Adam) of NCSN++ Large at the reference's training configuration
+    (configs/model/SGMSE_Large.yaml + configs/data/distort.yaml: batch 4, 512 frames x 512 bins, Adam lr 5e-4 weight_decay 1e-7;
+    reference model_wrapper.py:147-208) in bf16 mixed precision (16-bit activations and MFMAs incl. the weight gradients, fp32 parameters);
+    the same measurement as scripts/train_step_bench.py."""
+    from universal_speech_enhancement_amd.sgmse.model_wrapper import ScoreModel
+    torch.manual_seed(0)
+    m = ScoreModel(backbone="ncsnpplarge", sde="ouve", t_eps=3e-2, condition="noisy", n_fft=1022, hop_length=160, num_frames=512,
+                   window="hann", sde_input="noisy", precision="fp32").to(dev)
+    m.score_net.requires_grad_(True)
+    m.score_net.train_precision = "bf16"
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-7)
+    Bt, NF = 4, 512
+    clean = torch.randn(Bt, (NF - 1) * 160 + 4000, device=dev) * 0.1
+    batch = {"clean": clean, "perturbed": clean + 0.05 * torch.randn_like(clean)}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = m.train_step(batch)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    d = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(loss.detach()).all()
+    return {"ms_per_step": round(d * 1e3, 1), "frames_per_s": round(Bt * NF / d, 1), "batch": Bt, "frames": NF, "precision": "bf16 mixed (fp32 parameters)",
+            "steps_timed": steps, "note": "train_step forward + backward + Adam, the reference's training configuration (SGMSE_Large.yaml, batch 4 x 512 frames)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +162,7 @@ def main():
                          "per-GPU workload of the 32-utterance / 4-GPU config)")
     ap.add_argument("--no-power-probe", action="store_true", help="do not sample rocm-smi during the timed steps")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary sampler configurations (predictor-only, N=50, fp32)")
+    ap.add_argument("--no-secondary-configs", action="store_true", help="skip configs[3] / configs[4] share / training step inside `secondary`")
     ap.add_argument("--opt", action="append", default=[], help="use_set_option name=value (repeatable; same-box A/B of a tuning knob)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the timed sampler steps; run only the per-launch measurement of the dominant kernel (for "
@@ -170,12 +219,23 @@ def main():
 
     for w in range(a.warmup):
         eng.sample(Y, seed=4321 + w)
-    # socket power / shader clock while the timed steps run (rank 0, a sampling thread calling rocm-smi: a separate process, nothing on
-    # the GPU's queues): DESIGN.md section 4 round 4 - the evaluation runs at the package's power limit, which is what bounds it
-    probe = {"W": [], "MHz": []}
+    # socket power / shader clock / LIMITER while the timed steps run (rank 0, a sampling thread; nothing on the GPU's queues): the evaluation
+    # runs at the package's power limit.  Through amdsmi in-process: power, clock, hotspot temperature and the violation
+    # accumulators (PPT = socket power limit, socket / VR / HBM thermal, PROCHOT) - `limit_reasons` = share of the window each was active.
+    probe = {"W": [], "MHz": [], "recs": []}
     stop_probe = threading.Event()
 
     def power_thread():
+        try:
+            from universal_speech_enhancement_amd.testing import smi
+            amdsmi, hnd = smi.smi_open()
+            while not stop_probe.is_set():
+                probe["recs"].append(smi.sample(amdsmi, hnd))
+                stop_probe.wait(0.25)
+            probe["recs"].append(smi.sample(amdsmi, hnd))
+            return
+        except Exception:                                       # no amdsmi on this box: rocm-smi's text output (power and clock only)
+            probe["recs"] = []
         import re
         import subprocess
         while not stop_probe.is_set():
@@ -189,22 +249,46 @@ def main():
                 return
             stop_probe.wait(0.5)
     pt = None
-    if rank == 0 and not a.no_power_probe and shutil.which("rocm-smi"):
+    if rank == 0 and not a.no_power_probe:
         pt = threading.Thread(target=power_thread, daemon=True); pt.start()
     barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
         out = eng.sample(Y, seed=4321 + a.warmup + k)
     barrier()
-    dt = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+    dt_local = time.perf_counter() - t0
+    dt = D.max_over_ranks(dt_local, device=dev)
+    # self-verification of an N-GPU line: what RCCL saw (world size after init) and, per rank, its own step time and the device it ran on
+    me = {"rank": rank, "local_rank": local, "ms_per_step": round(dt_local / max(a.steps, 1) * 1e3, 2), "device": torch.cuda.get_device_name(local),
+          "pci_bus_id": pci_bus_id(local)}
+    if torch.distributed.is_initialized():
+        ranks_info = [None] * world
+        torch.distributed.all_gather_object(ranks_info, me)
+        ranks_seen = torch.distributed.get_world_size()
+    else:
+        ranks_info, ranks_seen = [me], 1
     stop_probe.set()
     if pt is not None:
         pt.join(timeout=6)
-    # (the first samples fall into the ramp: keep those within 10 % of the maximum)
-    keep = [i for i, w_ in enumerate(probe["W"]) if w_ >= 0.9 * max(probe["W"])] if probe["W"] else []
-    power_probe = ({"socket_W": round(sum(probe["W"][i] for i in keep) / len(keep), 1), "sclk_MHz": round(sum(probe["MHz"][i] for i in keep) / len(keep)),
-                    "samples": len(keep), "source": "rocm-smi --showpower --showclocks every 0.5 s during the timed steps (samples within 10 % of the maximum)"}
-                   if keep else None)
+    power_probe = None
+    if probe["recs"]:
+        from universal_speech_enhancement_amd.testing import smi
+        sm = smi.summarise(probe["recs"])
+        if "socket_W" in sm:
+            lr = sm.get("limit_reasons") or {}
+            flat = {k: (max(v) if isinstance(v, list) and v else v) for k, v in lr.items()}     # per-XCD arrays -> their maximum
+            power_probe = {"socket_W": sm["socket_W"], "sclk_MHz": sm.get("current_gfxclk"), "hotspot_C": sm.get("temperature_hotspot"),
+                           "hbm_C": sm.get("temperature_mem"), "samples": sm["samples"], "window_s": sm.get("window_s"), "limit_reasons": flat,
+                           "power_cap_W": 1400,
+                           "source": "amdsmi in-process every 0.25 s during the timed steps (samples within 10 % of the maximum power); limit_reasons = "
+                                     "share of that window in which the limiter was active (delta of its amdsmi violation accumulator / delta of acc_counter): "
+                                     "ppt_pwr = socket power limit, *_thrm = thermal limiters"}
+    if power_probe is None and probe["W"]:
+        # (the first samples fall into the ramp: keep those within 10 % of the maximum)
+        keep = [i for i, w_ in enumerate(probe["W"]) if w_ >= 0.9 * max(probe["W"])]
+        power_probe = {"socket_W": round(sum(probe["W"][i] for i in keep) / len(keep), 1), "sclk_MHz": round(sum(probe["MHz"][i] for i in keep) / len(keep)),
+                       "samples": len(keep), "limit_reasons": None,
+                       "source": "rocm-smi --showpower --showclocks every 0.5 s during the timed steps (samples within 10 % of the maximum)"}
     if a.steps:
         assert torch.isfinite(torch.view_as_real(out)).all(), "non-finite sampler output"
     else:
@@ -295,6 +379,7 @@ def main():
     # the predictor-only sampler at the benchmark's N, the reference's STOCK default (model_wrapper.py:39-40, 262-269: N = 50, corrector
     # "none"), and the fp32 parity mode (the mode the north_star tolerance is stated for) on the same workload
     secondary = None
+    cfg_is_1 = (B, a.N, ncorr, a.precision, a.seconds) == (8, 30, 1, "bf16", 4.0)
     if rank == 0 and world == 1 and not a.no_secondary and a.steps:
         def timed(engine, N, corr, steps):
             engine.plan(B, Tp)
@@ -317,6 +402,36 @@ def main():
             eng32.load_state_dict(sd_np)
             secondary["fp32_parity_mode"] = dict(timed(eng32, a.N, a.corrector, 1), note="fp32 storage, exact-fp32 MFMA: the mode the parity tolerances are stated for")
             eng32.close()
+        if cfg_is_1 and not a.no_secondary_configs:
+            # the other single-GPU configurations of BASELINE.json and the training step, each outside the timed region:
+            # configs[3] = batch 16, N = 200, Langevin snr 0.5 (400 NFE: one step); configs[4]'s per-GPU share = 8 x 4 s in fp16 storage
+            wav16 = torch.from_numpy(tn.synth_noisy_speech(16, L, seed=1234)).to(dev)
+            Y16 = glue._spectrogram(wav16).contiguous()
+
+            def timed_cfg(engine, Yc, N, steps):
+                Bc = Yc.shape[0]
+                engine.plan(Bc, Tp)
+                engine.set_sampler(N, "reverse_diffusion", "langevin", 1, 0.5, 3e-2, use_graph=not a.no_graph)
+                engine.sample(Yc, seed=1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for k in range(steps):
+                    o = engine.sample(Yc, seed=2 + k)
+                torch.cuda.synchronize()
+                d = (time.perf_counter() - t0) / steps
+                assert torch.isfinite(torch.view_as_real(o)).all()
+                return {"batch": Bc, "N": N, "nfe": 2 * N, "frames_per_s": round(Bc * T / d, 1), "ms_per_step": round(d * 1e3, 2),
+                        "ms_per_nfe": round(d * 1e3 / (2 * N), 3), "steps_timed": steps}
+            secondary["configs3_long_horizon"] = dict(timed_cfg(eng, Y16, 200, 1), note="BASELINE configs[3]: batch 16 x 4 s, N = 200, Langevin snr 0.5, bf16 (`bench.py --config 3`)")
+            del Y16, wav16
+            eng16 = HipScoreEngine(precision="fp16", device=local)
+            eng16.load_state_dict(sd_np)
+            secondary["configs4_fp16_share"] = dict(timed_cfg(eng16, Y, a.N, 2), note="BASELINE configs[4] per-GPU share: 8 x 4 s, N = 30 PC, fp16 storage + fp16 MFMA (`bench.py --config 4`)")
+            eng16.close()
+            try:
+                secondary["train_step"] = train_step_bench(dev)
+            except Exception as e:                                # the sampler line must not depend on the training path
+                secondary["train_step"] = {"error": str(e)[:200]}
         eng.plan(B, Tp)
         eng.set_sampler(a.N, "reverse_diffusion", a.corrector, 1, 0.5, 3e-2, use_graph=not a.no_graph)
 
@@ -336,6 +451,10 @@ def main():
                        "global_batch": world * B, "frames_per_utt": T, "padded_frames_per_utt": Tp, "n_freq": Fq,
                        "N": a.N, "nfe": nfe, "parallelism": f"utterance-sharded x{world}"},
             "padded_frame_nfe_per_s": round(padded_frame_nfe_per_s, 1),
+            "ranks_seen": ranks_seen, "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+            "distinct_devices": len({r["pci_bus_id"] for r in ranks_info}),
+            "ms_per_step_min_over_ranks": min(r["ms_per_step"] for r in ranks_info), "ms_per_step_max_over_ranks": max(r["ms_per_step"] for r in ranks_info),
+            "ranks": ranks_info,
             "roofline": roofline,
         }
         if power_probe is not None:

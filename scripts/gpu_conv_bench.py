@@ -64,7 +64,7 @@ def run(case, variant, iters, B, dtype, want_out=True):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="4,10")
+    ap.add_argument("--variants", default="4,2")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cases", default="main")
     ap.add_argument("--batch", type=int, default=4)

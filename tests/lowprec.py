@@ -13,10 +13,13 @@ Rules (each bound is a stated multiple of the reference-side figure):
   * one network evaluation: the HIP 16-bit mode may not be worse than the reference's own 16-bit run: factor 1.0 (the maximum over
     the stored t pairs) on the fixture's inputs; factor 1.25 on other inputs (measured 1.00 on tests/test_hip_fused_batch.py's) and for the
     long-sequence attention (1024 tokens, probabilities rounded to 16 bits for the P.V GEMM).
-  * chained sampler outputs (N evaluations, spectrogram or waveform): factor 2.5 of the reference's 60-evaluation chain figure.  The HIP
-    modes store EVERY activation tensor in 16 bits (that is what halves the HBM traffic), autocast rounds only the convolution /
-    matmul operands and keeps GroupNorm, SiLU and the residual sums in fp32; and the maximum is taken over up to 80x more elements
-    (B = 8, T' = 640 against the fixture's 1 x 64 frames).
+  * chained sampler outputs (N evaluations, spectrogram or waveform): factor 2.25 (rel-max) / 1.75 (rel-L2) of the reference's
+    60-evaluation chain figure (round 5; rounds 3-4 allowed 2.5 for both).  Largest ratios measured so far (GPUTEST r04 + round 5):
+    rel-max 1.94 (fp16 spectrogram, configs[1]: B = 8, T' = 640), 1.81 (bf16 waveform, same run), 1.60 (one item of the B = 8 Langevin
+    test); rel-L2 1.56 (fp16 spectrogram, configs[1]), 1.39 (bf16).  Why above 1: the HIP modes store EVERY activation tensor in 16 bits
+    (that is what halves the HBM traffic) while autocast rounds only the convolution / matmul operands and keeps GroupNorm, SiLU and the
+    residual sums in fp32; and the rel-max is a maximum over up to 80x more elements (B = 8, T' = 640 against the fixture's 1 x 64
+    frames) - which is why VERDICT r4's suggested 1.75 / 1.5 (derived from one 1.4 reading) would fail on two of the eight cfg2 figures.
   * fp16 figures that the CPU cannot produce (training backward) are the bf16 figures / 4 (three more mantissa bits = 8x, halved for
     the same storage argument).
   * single operators: k units in the last place of the storage type relative to the tensor maximum (bf16: 2^-8, fp16: 2^-11), k = 4:
@@ -45,9 +48,12 @@ def refine_bound(prec: str = "bf16", factor: float = 1.0) -> float:
     return factor * max(ref16(f"refine_{prec}_relmax_golden"), ref16(f"refine_{prec}_relmax_t128"))
 
 
-def chain_bound(prec: str, what: str, norm: str, factor: float = 2.5) -> float:
+CHAIN_FACTOR = {"relmax": 2.25, "rell2": 1.75}
+
+
+def chain_bound(prec: str, what: str, norm: str, factor: float = None) -> float:
     """what: 'spec' | 'wav'; norm: 'relmax' | 'rell2'."""
-    return factor * ref16(f"chain_{prec}_{what}_{norm}")
+    return (CHAIN_FACTOR[norm] if factor is None else factor) * ref16(f"chain_{prec}_{what}_{norm}")
 
 
 def train_bound(prec: str, what: str, factor: float = 1.0) -> float:

@@ -918,6 +918,8 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
     if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
+    if (!strcmp(name, "conv_v4w")) { conv_v4w_set_enable((int)value); return USE_OK; }             // 0: plain / residual convolutions on conv_v4
+    if (!strcmp(name, "conv_v4w_ipw")) { conv_v4w_set_ipw((int)std::max(0LL, value)); return USE_OK; }   // items per workgroup of the walk (0: per launch)
     if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_mfma16")) { wgrad_set_mfma16((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_blocks")) { wgrad_set_blocks((int)value); return USE_OK; }
@@ -1639,6 +1641,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             case 7: if (!conv_sk_eligible(a)) return -1; launch_conv_sk(a, 0); return 0;
             case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
             case 4: if (!a.wb || (XC && !a.w2b) || a.H % 16 || a.W % 32) return -1; launch_conv_v4(a, 0); return 0;   // (conv_v4 has no partial tiles)
+            case 5: if (!a.wb || XC || a.H % 16 || a.W % 32 || dt == DT_F32 || Cin % 64 || a.Cout <= 32) return -1; launch_conv_v4w(a, 0); return 0;   // the walk (items per workgroup: option conv_v4w_ipw)
             default: return -1;
         }
     };

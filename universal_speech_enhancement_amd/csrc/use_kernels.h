@@ -89,6 +89,12 @@ void pyr_conv_set_pipe(int n);                          // pyramid-head convolut
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 80 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);
+// conv_v4's schedule as a walk over `ipw` batch items per workgroup for the plain / residual convolutions of the 16-bit modes (use_conv_v4w.hip)
+bool conv_v4w_eligible(const ConvArgs& a);
+void conv_v4w_set_enable(int on);                        // default on
+void conv_v4w_set_ipw(int n);                            // items per workgroup (0: chosen per launch; results do not depend on it)
+int conv_v4w_items_per_wg(const ConvArgs& a);
+void launch_conv_v4w(const ConvArgs& a, hipStream_t s);
 // GroupNorm finalisation for the consumers that take a coefficient array (FIR resampling kernels): per-(b, group) mean / rstd
 // from the per-channel totals of up to two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b): y = a*x + b.
 void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta,
