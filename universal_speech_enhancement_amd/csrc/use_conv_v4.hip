@@ -26,7 +26,11 @@ constexpr int V4_TW = 32, V4_TH = 16;             // tile: 16 rows x 32 columns
 constexpr int V4_HW = V4_TW + 2, V4_HH = V4_TH + 2;
 constexpr int V4_BN = 128;
 #ifndef V4_ABL                      /* timing-only ablation builds (results wrong): bit 1 transform off, 2 no halo loads / piece stores, */
-#define V4_ABL 0                    /* 4 no weight loads / stores, 8 no fragment reads, 16 no epilogue, 32 no chunk-0 staging in the prologue */
+#define V4_ABL 0                    /* 4 no weight loads / stores, 8 no fragment reads, 16 no epilogue, 32 no chunk-0 staging in the prologue; */
+                                    /* epilogue parts: 1024 no output stores, 2048 no LDS transposition, 4096 no statistics, 8192 no residual loads */
+#endif
+#ifndef V4_DEAD_LOADS               /* 1: the loads of the last K chunk's staging pass (results unused) go through an empty buffer descriptor */
+#define V4_DEAD_LOADS 1
 #endif
 #ifdef USE_HIP_XF_LEGACY            /* A/B builds only: the round 1-3 form (transform left to the compiler's scheduling) */
 constexpr bool V4_XF_LEGACY = true;
@@ -150,18 +154,21 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         for (int k = 0; k < VEC; ++k) { const float2 v = cf[k]; ca[k] = v.x; cb[k] = v.y; }
     };
     // buffer loads: tensor descriptor + uniform SGPR offset + 32-bit lane offset
-    auto buf_ld = [&](const void* base, unsigned voff, unsigned soff) -> uint4 {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+    // `live` (uniform): 0 makes the descriptor EMPTY (num_records 0) - every lane is out of range, the load returns zeros and fetches nothing.
+    // That is how the staging pass of the LAST K chunk (nothing left to stage; its loads stay unconditional because a load on one
+    // control-flow path costs hipcc's counted waits) is kept off the memory system: round 5, V4_DEAD_LOADS.
+    auto buf_ld = [&](const void* base, unsigned voff, unsigned soff, int live = 1) -> uint4 {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, live ? 0x7fffffff : 0, 0x00020000);
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
     };
-    auto src_ld0 = [&](int chunk, int pixoff) -> uint4 {
+    auto src_ld0 = [&](int chunk, int pixoff, int live = 1) -> uint4 {
         const int c_glob = chunk * CK;
         const TIN* src; int Cs, c_loc;
         if (c_glob < p.C0) { src = (const TIN*)p.src0; Cs = p.C0; c_loc = c_glob; }
         else               { src = (const TIN*)p.src1; Cs = p.C1; c_loc = c_glob - p.C0; }
         const unsigned voff = (unsigned)pixoff * (unsigned)(Cs * (int)sizeof(TIN)) + (unsigned)(part * 16);
         // per-item buffer base: the 32-bit offsets only have to span one image (any batch size, < 2 GB per image tensor)
-        return buf_ld(src + (size_t)b * p.H * p.W * Cs, voff, (unsigned)(c_loc * (int)sizeof(TIN)));
+        return buf_ld(src + (size_t)b * p.H * p.W * Cs, voff, (unsigned)(c_loc * (int)sizeof(TIN)), live);
     };
     // ---- segment-1 (shortcut) pieces: the 16x32 centre pixels, 4 per thread, raw ----------------------------------------
     auto load_piece1 = [&](int chunk2, int q, uint4& raw) -> unsigned {
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         const int cw0_ = (TT) > 8 ? (CC) + 1 : (CC);                                                                 \
         const int cw_ = cw0_ < nchunks ? cw0_ : nchunks - 1; /* past the end: a harmless re-load (NO branch: a load on one  */ \
         const int tw_ = (TT) > 8 ? (TT)-9 : (TT);            /* control-flow path only turns hipcc's next wait into vmcnt(0)) */ \
-        R = buf_ld(p.wb, wvoff, (unsigned)(tw_ * nchunks + cw_) * slab_b + n0_b);                                    \
+        R = buf_ld(p.wb, wvoff, (unsigned)(tw_ * nchunks + cw_) * slab_b + n0_b, V4_DEAD_LOADS ? (cw0_ < nchunks) : 1);       \
     }
 #define V4_STORE_W(BUF, R) { *reinterpret_cast<uint4*>(smem + (BUF)*W_BYTES + wdst) = R; }
 
@@ -287,7 +294,20 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
 #else
 #define V4_SETPRIO(N)
 #endif
-#define V4_XF_PHASE(T) ((T) >= 2 && (T) < PIECE_ITERS + 2)   /* MFMA(T) carries the transform of piece T - 2 */
+    // V4_PEEL_LAST (round 5): the last K chunk of a segment has nothing to stage - its staging pass (five halo loads, their transforms and
+    // stores: a quarter of the loop's staging work at Cin = 128) used to run anyway because a load on one control-flow path costs hipcc's
+    // counted waits.  Peeled: the chunk loop runs nchunks - 1 times with staging and the last chunk is a second copy of the code without.
+    // Pieces are then loaded in LDS(1..5) and transformed in MFMA(3..7) (V4_P0 = 1), so that LDS(c, 0) - which group 0 issues at the end of
+    // chunk c - 1 - carries no load and needs no copy of its own.
+#ifdef V4_PEEL_LAST
+#define V4_P0 1
+#else
+#define V4_P0 0
+#define V4_STG 1
+#endif
+#define V4_LD_PHASE(T) (V4_STG && (T) >= V4_P0 && (T) < PIECE_ITERS + V4_P0)            /* LDS(T) issues the load of piece T - V4_P0 */
+#define V4_XF_PHASE(T) (V4_STG && (T) >= V4_P0 + 2 && (T) < PIECE_ITERS + V4_P0 + 2)   /* MFMA(T) carries the transform of piece T - V4_P0 - 2 */
+#define V4_XF_IDX(T) (V4_XF_PHASE(T) ? (T) - V4_P0 - 2 : 0)
 #define V4_LDS(CC, T)                                                                                                \
     {                                                                                                                \
         const int cc_ = (CC);                                                                                        \
@@ -295,8 +315,8 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         const int cn_ = cc_ + 1 < nchunks ? cc_ + 1 : cc_;   /* chunk being staged (last chunk: itself again, results unused - */ \
         int pix_ = 0;                                        /* everything below is unconditional, see V4_LOAD_W)             */ \
         /* table entries first: they return ahead of the fragments */                                                \
-        if ((T) < PIECE_ITERS) pix_ = (V4_ABL & 128) ? tid * 3 : pix_tab[((T) < PIECE_ITERS ? (T) : 0) * 512 + tid]; \
-        if (V4_XF_PHASE(T)) dst_ = (V4_ABL & 128) ? tid * 80 : dst_tab[(V4_XF_PHASE(T) ? (T)-2 : 0) * 512 + tid];    \
+        if (V4_LD_PHASE(T)) pix_ = (V4_ABL & 128) ? tid * 3 : pix_tab[(V4_LD_PHASE(T) ? (T) - V4_P0 : 0) * 512 + tid]; \
+        if (V4_XF_PHASE(T)) dst_ = (V4_ABL & 128) ? tid * 80 : dst_tab[V4_XF_IDX(T) * 512 + tid];    \
         {                                                                                                            \
             const char* ha_ = smem + par_ * HALO_BYTES + ((T) / 3) * HPITCH;                                         \
             const char* wbuf_ = smem + (par_ ^ ((T)&1)) * W_BYTES;                                                   \
@@ -310,7 +330,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
             }                                                                                                        \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if ((V4_ABL & 512) && (T) >= 3 && (T) < PIECE_ITERS + 3) *reinterpret_cast<uint4*>(smem + dkeep) = tkeep;    \
+        if ((V4_ABL & 512) && (T) >= 3 + V4_P0 && (T) < PIECE_ITERS + 3 + V4_P0) *reinterpret_cast<uint4*>(smem + dkeep) = tkeep;    \
         if (V4_XF_PHASE(T)) dst_ += (par_ ^ 1) * HALO_BYTES; /* where MFMA(T) puts its transformed piece */          \
         if ((V4_ABL & 256) && V4_XF_PHASE(T)) dst_ = (par_ ^ 1) * HALO_BYTES + tid * 16;                             \
         if (!(V4_ABL & 4)) {                                                                                         \
@@ -318,9 +338,9 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         V4_LOAD_W(cc_, (T) + 2, wS);                                                                                 \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                   /* the slab load stays older than the halo load */      \
-        if ((T) < PIECE_ITERS) {                                                                                     \
-            if ((T) == 0) load_coef(cn_);                                                                            \
-            hL[(T) % 3] = src_ld0(cn_, pix_);                                                                          \
+        if (V4_LD_PHASE(T)) {                                                                                        \
+            if ((T) == V4_P0) load_coef(cn_);                                                                        \
+            hL[((T) - V4_P0) % 3] = src_ld0(cn_, pix_, V4_DEAD_LOADS ? (cc_ + 1 < nchunks) : 1);                                                         \
         }                                                                                                            \
     }
 #define V4_MFMA(CC, T)                                                                                               \
@@ -331,15 +351,15 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
                 /* 16 MFMAs, slice g of the GroupNorm + SiLU transform of one halo piece behind MFMA g, one asm statement */ \
                 /* each (use_device.h, XfAsm: left to itself hipcc runs the transform with the matrix pipe idle)          */ \
                 V4_PSTAMP_C(CC, 300 + (T))                        /* trace builds: 3xx -> 4xx = the exposed wait for the halo piece */ \
-                V4_TRACE_FORCE(hL[(V4_XF_PHASE(T) ? (T)-2 : 0) % 3])                                                 \
+                V4_TRACE_FORCE(hL[V4_XF_IDX(T) % 3])                                                 \
                 V4_PSTAMP_C(CC, 400 + (T))                                                                               \
                 if (V4_ABL & 1) {                                                                                    \
                     _Pragma("unroll") for (int kk = 0; kk < KSTEPS; ++kk)                                            \
                         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                               \
                             _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);  \
-                    if (!(V4_ABL & 64)) *reinterpret_cast<uint4*>(smem + dst_) = hL[(V4_XF_PHASE(T) ? (T)-2 : 0) % 3];  \
+                    if (!(V4_ABL & 64)) *reinterpret_cast<uint4*>(smem + dst_) = hL[V4_XF_IDX(T) % 3];  \
                 } else {                                                                                             \
-                const uint4 t0 = mfma16_with_transform<TIN, ACT>(acc, af, bf, hL[(V4_XF_PHASE(T) ? (T)-2 : 0) % 3], ca, cb); \
+                const uint4 t0 = mfma16_with_transform<TIN, ACT>(acc, af, bf, hL[V4_XF_IDX(T) % 3], ca, cb); \
                 if (V4_ABL & 512) { tkeep = t0; asm volatile("" : "+v"(tkeep.x), "+v"(tkeep.y), "+v"(tkeep.z), "+v"(tkeep.w)); dkeep = dst_; } \
                 else if (!(V4_ABL & 64)) *reinterpret_cast<uint4*>(smem + dst_) = t0; /* the other halo buffer: nobody reads it during this chunk */ \
                 }                                                                                                    \
@@ -353,7 +373,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
                 _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                       \
                     _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);  \
             if (V4_XF_PHASE(T)) {                                                                                    \
-                const uint4 t0 = stage_transform<TIN, ACT>(hL[(V4_XF_PHASE(T) ? (T)-2 : 0) % 3], 0xffffffffu, ca, cb); \
+                const uint4 t0 = stage_transform<TIN, ACT>(hL[V4_XF_IDX(T) % 3], 0xffffffffu, ca, cb); \
                 *reinterpret_cast<uint4*>(smem + dst_) = t0;                                                         \
                 _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                     \
                     __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * KSTEPS / 16, 0);   /* MFMA  */             \
@@ -376,28 +396,52 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     V4_STAMP(2)
     V4_BAR();
     V4_STAMP(3)
+#define V4_G0_CHUNK(LAST)                                                                                            \
+            V4_STAMP(50 + c)                                                                                         \
+            V4_G0_STEP(0) V4_G0_STEP(1) V4_G0_STEP(2) V4_G0_STEP(3) V4_G0_STEP(4) V4_G0_STEP(5) V4_G0_STEP(6) V4_G0_STEP(7) \
+            V4_MFMA(c, 8)                                                                                            \
+            V4_BAR_M();                                                                                              \
+            if (!(LAST) && c + 1 < nchunks) V4_LDS(c + 1, 0)    /* (uniform; the last chunk has nothing left to read) */ \
+            V4_BAR();
+#define V4_G0_STEP(T) V4_MFMA(c, T) V4_PSTAMP(100 + (T)) V4_BAR_M(); V4_LDS(c, (T) + 1) V4_PSTAMP(200 + (T) + 1) V4_BAR();
+#define V4_G1_STEP(T) V4_LDS(c, T) V4_PSTAMP(200 + (T)) V4_BAR(); V4_MFMA(c, T) V4_PSTAMP(100 + (T)) V4_BAR_M();
+#define V4_G1_CHUNK                                                                                                  \
+            V4_STAMP(50 + c)                                                                                         \
+            V4_G1_STEP(0) V4_G1_STEP(1) V4_G1_STEP(2) V4_G1_STEP(3) V4_G1_STEP(4) V4_G1_STEP(5) V4_G1_STEP(6) V4_G1_STEP(7) V4_G1_STEP(8)
+#ifdef V4_PEEL_LAST
+#define V4_STG 1
     if (wave < 4) {
         V4_LDS(0, 0)
         V4_BAR();
-        for (int c = 0; c < nchunks; ++c) {
-            V4_STAMP(50 + c)
-#define V4_G0_STEP(T) V4_MFMA(c, T) V4_PSTAMP(100 + (T)) V4_BAR_M(); V4_LDS(c, (T) + 1) V4_PSTAMP(200 + (T) + 1) V4_BAR();
-            V4_G0_STEP(0) V4_G0_STEP(1) V4_G0_STEP(2) V4_G0_STEP(3) V4_G0_STEP(4) V4_G0_STEP(5) V4_G0_STEP(6) V4_G0_STEP(7)
-#undef V4_G0_STEP
-            V4_MFMA(c, 8)
-            V4_BAR_M();
-            if (c + 1 < nchunks) V4_LDS(c + 1, 0)           // (uniform; the last chunk has nothing left to read)
-            V4_BAR();
-        }
+        for (int c = 0; c < nchunks - 1; ++c) { V4_G0_CHUNK(false) }
+#undef V4_STG
+#define V4_STG 0
+        { const int c = nchunks - 1; V4_G0_CHUNK(true) }   /* (its own constant, not the loop's counter: that one hipcc treats as divergent - waterfall loops) */
     } else {
         V4_BAR();
-        for (int c = 0; c < nchunks; ++c) {
-            V4_STAMP(50 + c)
-#define V4_G1_STEP(T) V4_LDS(c, T) V4_PSTAMP(200 + (T)) V4_BAR(); V4_MFMA(c, T) V4_PSTAMP(100 + (T)) V4_BAR_M();
-            V4_G1_STEP(0) V4_G1_STEP(1) V4_G1_STEP(2) V4_G1_STEP(3) V4_G1_STEP(4) V4_G1_STEP(5) V4_G1_STEP(6) V4_G1_STEP(7) V4_G1_STEP(8)
-#undef V4_G1_STEP
-        }
+#undef V4_STG
+#define V4_STG 1
+        for (int c = 0; c < nchunks - 1; ++c) { V4_G1_CHUNK }
+#undef V4_STG
+#define V4_STG 0
+        { const int c = nchunks - 1; V4_G1_CHUNK }
     }
+#undef V4_STG
+#define V4_STG 1
+#else
+    if (wave < 4) {
+        V4_LDS(0, 0)
+        V4_BAR();
+        for (int c = 0; c < nchunks; ++c) { V4_G0_CHUNK(false) }
+    } else {
+        V4_BAR();
+        for (int c = 0; c < nchunks; ++c) { V4_G1_CHUNK }
+    }
+#endif
+#undef V4_G0_STEP
+#undef V4_G1_STEP
+#undef V4_G0_CHUNK
+#undef V4_G1_CHUNK
 #undef V4_BAR
 #undef V4_BAR_M
 #undef V4_LDS
@@ -502,8 +546,9 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         if (has_res) {
 #pragma unroll
             for (int q = 0; q < QN; ++q)
-                resv[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff + row_b + (unsigned)q * pass_b, 0, 0));
+                resv[q] = (V4_ABL & 8192) ? make_uint4(q, q, q, q) : __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff + row_b + (unsigned)q * pass_b, 0, 0));
         }
+        if (!(V4_ABL & 2048)) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -512,13 +557,15 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
                 stg[row * STG_LD + j * 32 + (lane & 31)] = acc[i][j][r];
             }
         __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
             const int row = (q * 64 + lane) / CPR;           // pixel column inside the tile row
             float v[CH];
 #pragma unroll
             for (int c4 = 0; c4 < CH / 4; ++c4) {
-                const float4 t4 = *reinterpret_cast<const float4*>(stg + row * STG_LD + ch * CH + c4 * 4);
+                const float4 t4 = (V4_ABL & 2048) ? make_float4(acc[i][c4 & 3][q & 15], acc[i][(c4 + 1) & 3][(q + 1) & 15], acc[i][(c4 + 2) & 3][(q + 2) & 15], acc[i][(c4 + 3) & 3][(q + 3) & 15])
+                                                  : *reinterpret_cast<const float4*>(stg + row * STG_LD + ch * CH + c4 * 4);
                 v[c4 * 4] = t4.x; v[c4 * 4 + 1] = t4.y; v[c4 * 4 + 2] = t4.z; v[c4 * 4 + 3] = t4.w;
             }
             if (has_res) {
@@ -544,16 +591,24 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
                 const uint4 packed = Vec16<TOUT>::pack(v);
                 // (voffset carries the whole offset: with the uniform part in soffset, hipcc 7.2 mis-assigns the SGPR of one pass in
                 // the 16-pass fp32 instantiation - one VALU add per pass is the price of not depending on that)
+                if (V4_ABL & 1024) asm volatile("" :: "v"(packed.x), "v"(packed.y), "v"(packed.z), "v"(packed.w));
+                else
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, packed), rs_out,
                                                        voff + row_b + (unsigned)q * pass_b, 0, 0);
+                if (!(V4_ABL & 4096)) {
 #pragma unroll
                 for (int c = 0; c < CH; ++c) { st_s[c] += v[c]; st_q[c] = fmaf(v[c], v[c], st_q[c]); }
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
         V4_STAMP(7)
     }
-    if (p.stats) {
+    if ((V4_ABL & 65536)) { float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) t += st_s[c] + st_q[c];
+        asm volatile("" :: "v"(t)); }
+    if ((p.stats || p.stats_part) && !(V4_ABL & (4096 | 65536))) {
         // lanes holding the same 16-byte channel chunk are CPR apart inside a wave
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -575,7 +630,13 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
 #pragma unroll
             for (int w = 0; w < 8; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
             const int co = n0 + tid;
-            if (co < p.Cout) gn_accumulate(p.stats + ((size_t)b * p.Cout + co) * 2, s, q);
+            if (V4_ABL & 32768) asm volatile("" :: "v"(s), "v"(q));
+            else if (co < p.Cout) {
+                if (p.stats_part) {                          // this workgroup's partial totals, plain 16-byte store (no queue on the item's totals)
+                    long long* d = p.stats_part + (((size_t)b * gridDim.x + blockIdx.x) * p.Cout + co) * 2;
+                    *reinterpret_cast<longlong2*>(d) = make_longlong2(__float2ll_rn(s * GN_SUM_SCALE), __float2ll_rn(q * GN_SQ_SCALE));
+                } else gn_accumulate(p.stats + ((size_t)b * p.Cout + co) * 2, s, q);
+            }
         }
     }
     V4_STAMP(8)

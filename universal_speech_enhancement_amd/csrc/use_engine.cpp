@@ -86,7 +86,8 @@ struct Expected { std::string name; std::vector<int64_t> shape; };
 
 constexpr int MAX_SUB = 4;                       // sub-batches of the pipelined evaluation (run_score)
 
-struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, dtype = DT_F32; long long* stats = nullptr; };   // stats: [B][C][2] fixed-point totals
+struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, dtype = DT_F32; long long* stats = nullptr;     // stats: [B][C][2] fixed-point totals
+             long long* part = nullptr; int ntiles = 0; };   // or (large maps, conv_v4 producers) [B][ntiles][C][2] per-workgroup partial totals (ConvArgs::stats_part)
 
 struct Arena {
     char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
@@ -432,6 +433,7 @@ static int g_subbatch = 2;                       // use_set_option("subbatch", n
 // small, latency-bound maps the saved launch is what counts.  use_set_option("gn_inline", pixels); 0: never inline
 static long g_gn_inline = 128L * 160L;
 static int g_attn_fused = 1;                     // use_set_option("attn_fused", 0): the unfused attention block (3 NIN, core, NIN_3)
+static int g_stats_part = 1;                     // use_set_option("stats_part", 0): GroupNorm totals by atomics on the large maps too
 static int g_stagger_level = 2;                  // use_set_option("stagger_level", l): the next sub-batch starts after level l
 
 __global__ __launch_bounds__(256) void zero16_kernel(uint4* __restrict__ p, size_t n16) {
@@ -473,7 +475,7 @@ struct Fwd {
         float* coef = (float*)arena->alloc((size_t)B * C * 2 * 4);
         if (!h->dry)
             launch_gn_finalize(a.stats, a.C, a2 ? a2->stats : nullptr, a2 ? a2->C : 0, W<float>(g.g_off), W<float>(g.b_off),
-                               std::min(C / 4, 32), a.H * a.W, 1e-6f, coef, B, s);
+                               std::min(C / 4, 32), a.H * a.W, 1e-6f, coef, B, s, a.part, a.ntiles, a2 ? a2->part : nullptr, a2 ? a2->ntiles : 0);
         return coef;
     }
 
@@ -487,6 +489,10 @@ struct Fwd {
         h->flops += fl;
         // large maps: separate finalize launch into a coefficient array (allocated in the dry run as well: the arena is sized by it)
         const float* coef_arr = (gn && (long)a.H * a.W > g_gn_inline) ? gn_coef(a, a2, *gn) : nullptr;
+        // Large maps: the producer writes per-workgroup partial totals instead of queueing 640 atomics per item on each total; every consumer
+        // of such a map goes through gn_coef (same threshold), which sums them.  (allocated in the dry run as well: the arena is sized by it)
+        long long* part = (stats && g_stats_part && (long)a.H * a.W > g_gn_inline)
+                              ? (long long*)arena->alloc((size_t)B * conv_v4_tiles(a.H, a.W) * w.cout * 2 * sizeof(long long)) : nullptr;
         if (h->dry) return o;
         ConvArgs p{};
         p.src0 = a.p; p.C0 = a.C; p.src1 = a2 ? a2->p : nullptr; p.C1 = a2 ? a2->C : 0; p.in_dtype = a.dtype;
@@ -507,6 +513,7 @@ struct Fwd {
         p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
         p.B = B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
         const bool main_variant = conv_v4_eligible(p);        // the dominant kernel (conv_v4_kernel, large maps)
+        if (part && main_variant) { p.stats_part = part; p.stats = nullptr; o.part = part; o.ntiles = conv_v4_tiles(a.H, a.W); }
         if (h->profile && (main_variant || (h->profile_all && conv_v2_eligible(p)))) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, s);
@@ -664,6 +671,7 @@ struct Fwd {
                         launch_combine_add(o.p, o.dtype, (const float*)ipyr.p, W<float>(cb.w_off), W<float>(cb.b_off), o.stats, B,
                                            (long)o.H * o.W, o.C, s);
                     }
+                    o.part = nullptr; o.ntiles = 0;            // (the totals of the combined map are what the consumers read)
                     hs.push_back(o);
                 }
             }
@@ -916,10 +924,9 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "plan_cache")) { g_plan_cache = (int)std::max(0LL, std::min(16LL, value)); return USE_OK; }   // parked plans per handle
     if (!strcmp(name, "subbatch")) { g_subbatch = (int)value; return USE_OK; }          // takes effect at the next use_plan
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
+    if (!strcmp(name, "stats_part")) { g_stats_part = (int)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
-    if (!strcmp(name, "conv_v4w")) { conv_v4w_set_enable((int)value); return USE_OK; }             // 0: plain / residual convolutions on conv_v4
-    if (!strcmp(name, "conv_v4w_ipw")) { conv_v4w_set_ipw((int)std::max(0LL, value)); return USE_OK; }   // items per workgroup of the walk (0: per launch)
     if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_mfma16")) { wgrad_set_mfma16((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_blocks")) { wgrad_set_blocks((int)value); return USE_OK; }
@@ -1641,7 +1648,6 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             case 7: if (!conv_sk_eligible(a)) return -1; launch_conv_sk(a, 0); return 0;
             case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
             case 4: if (!a.wb || (XC && !a.w2b) || a.H % 16 || a.W % 32) return -1; launch_conv_v4(a, 0); return 0;   // (conv_v4 has no partial tiles)
-            case 5: if (!a.wb || XC || a.H % 16 || a.W % 32 || dt == DT_F32 || Cin % 64 || a.Cout <= 32) return -1; launch_conv_v4w(a, 0); return 0;   // the walk (items per workgroup: option conv_v4w_ipw)
             default: return -1;
         }
     };

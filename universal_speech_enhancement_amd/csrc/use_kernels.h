@@ -67,6 +67,9 @@ struct ConvArgs {
     const float* w4;        // [Cout][4]
     const float* b4;        // [Cout]
     void* out; int out_dtype;
+    long long* stats_part;  // or null: [B][conv_v4_tiles][Cout][2] per-workgroup partial totals in the format of `stats`, written with plain stores
+                            // INSTEAD of the atomics below (conv_v4 on the large maps: 640 workgroups per item finishing in step queue
+                            // 64 deep on each of an item's 256 totals - measured 3.3 % of a launch); gn_finalize sums them (launch_gn_finalize)
     long long* stats;       // or null: [B][Cout][2] fixed-point totals (sum * 2^20, sum of squares * 2^20) of the stored values,
                             // accumulated with 64-bit integer atomics (order-independent, hence deterministic); zeroed by the caller
     int B, H, W, Cout, ntaps;
@@ -89,16 +92,13 @@ void pyr_conv_set_pipe(int n);                          // pyramid-head convolut
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 80 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);
-// conv_v4's schedule as a walk over `ipw` batch items per workgroup for the plain / residual convolutions of the 16-bit modes (use_conv_v4w.hip)
-bool conv_v4w_eligible(const ConvArgs& a);
-void conv_v4w_set_enable(int on);                        // default on
-void conv_v4w_set_ipw(int n);                            // items per workgroup (0: chosen per launch; results do not depend on it)
-int conv_v4w_items_per_wg(const ConvArgs& a);
-void launch_conv_v4w(const ConvArgs& a, hipStream_t s);
 // GroupNorm finalisation for the consumers that take a coefficient array (FIR resampling kernels): per-(b, group) mean / rstd
 // from the per-channel totals of up to two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b): y = a*x + b.
+// Source i is given either as totals st_i [B][C_i][2] or (pt_i != null) as nt_i per-workgroup partial totals pt_i [B][nt_i][C_i][2]
+// (ConvArgs::stats_part): integer sums, so both forms give bit-identical coefficients.
 void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta,
-                        int groups, int hw, float eps, float* coef, int B, hipStream_t s);
+                        int groups, int hw, float eps, float* coef, int B, hipStream_t s, const long long* pt0 = nullptr, int nt0 = 0,
+                        const long long* pt1 = nullptr, int nt1 = 0);
 
 // FIR x2 resampling with the separable [1,3,3,1] kernel (upfirdn2d semantics of the reference).
 // out_act (nullable) = FIR(act(a*x+b)), out_raw (nullable) = FIR(x).

@@ -893,7 +893,6 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     }
 #endif
     if (conv_sk_eligible(a)) { launch_conv_sk(a, s); return; }
-    if (conv_v4w_eligible(a)) { launch_conv_v4w(a, s); return; }
     if (conv_v4_eligible(a)) { launch_conv_v4(a, s); return; }
     if (conv_v2_eligible(a)) { launch_conv_v2(a, s); return; }
     launch_conv_generic(a, s);
@@ -990,10 +989,56 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const long long* __res
     }
 }
 
+// The same from per-workgroup partial totals (ConvArgs::stats_part): one block per (item, group); the threads walk the group's
+// (channel, workgroup) pairs, the integer sums are order-independent, the arithmetic behind them is gn_coef_of's.
+__global__ __launch_bounds__(256) void gn_finalize_part_kernel(const long long* __restrict__ st0, const long long* __restrict__ pt0, int nt0, int C0,
+                                                               const long long* __restrict__ st1, const long long* __restrict__ pt1, int nt1, int C1,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int groups,
+                                                               float inv_n, float eps, float* __restrict__ coef) {
+    const int b = blockIdx.x, g = blockIdx.y, C = C0 + C1, cpg = C / groups, c0 = g * cpg;
+    long long S = 0, Q = 0;
+    for (int k = 0; k < cpg; ++k) {
+        const int cc = c0 + k;
+        const bool first = cc < C0;
+        const long long* pt = first ? pt0 : pt1;
+        const int Cs = first ? C0 : C1, cl = first ? cc : cc - C0, nt = first ? nt0 : nt1;
+        if (pt) {
+            for (int t = threadIdx.x; t < nt; t += 256) {
+                const long long* q = pt + (((size_t)b * nt + t) * Cs + cl) * 2;
+                S += q[0]; Q += q[1];
+            }
+        } else if (threadIdx.x == 0) {
+            const long long* q = (first ? st0 : st1) + ((size_t)b * Cs + cl) * 2;
+            S += q[0]; Q += q[1];
+        }
+    }
+    __shared__ long long red[2][4];
+    for (int o = 32; o > 0; o >>= 1) { S += __shfl_xor(S, o); Q += __shfl_xor(Q, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = S; red[1][threadIdx.x >> 6] = Q; }
+    __syncthreads();
+    if (threadIdx.x < cpg) {
+        S = red[0][0] + red[0][1] + red[0][2] + red[0][3]; Q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double mean = (double)S * (1.0 / 1048576.0) * (double)inv_n;                // (gn_coef_of, use_device.h)
+        double var = (double)Q * (1.0 / 1048576.0) * (double)inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float v = (float)var + eps;
+        float rstd = __builtin_amdgcn_rsqf(v);
+        rstd = rstd * (1.5f - 0.5f * v * rstd * rstd);
+        const int c = c0 + threadIdx.x;
+        const float a = gamma[c] * rstd;
+        coef[((size_t)b * C + c) * 2] = a;
+        coef[((size_t)b * C + c) * 2 + 1] = beta[c] - (float)mean * a;
+    }
+}
+
 void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int C1, const float* gamma, const float* beta,
-                        int groups, int hw, float eps, float* coef, int B, hipStream_t s) {
+                        int groups, int hw, float eps, float* coef, int B, hipStream_t s, const long long* pt0, int nt0,
+                        const long long* pt1, int nt1) {
     const float inv_n = 1.0f / ((float)((C0 + C1) / groups) * (float)hw);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, st0, C0, st1, C1, gamma, beta, groups, inv_n, eps, coef);
+    if (pt0 || pt1)
+        hipLaunchKernelGGL(gn_finalize_part_kernel, dim3(B, groups), dim3(256), 0, s, st0, pt0, nt0, C0, st1, pt1, nt1, C1, gamma, beta, groups, inv_n, eps, coef);
+    else
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, st0, C0, st1, C1, gamma, beta, groups, inv_n, eps, coef);
 }
 
 // ---------------------------------------------------------------------------------------------------------
