@@ -888,6 +888,52 @@ def test_conv_sk_matches_the_generic_kernel(dtype, tol):
         assert np.abs(sk[1] - ref[1]).max() <= 1e-3 * np.abs(ref[1]).max()
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
+def test_two_handles_on_two_devices_in_one_process(sd_np):
+    """include/use_hip.h: one handle per (process, device).  hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of (kernel,
+    device): rounds 1-4 cached it in one flag per process, so the second device's > 64 KB-LDS kernels (conv_v4, conv_v2, the attention
+    block, the pyramid heads) would have been launched unprepared.  Both devices must produce the same score, bit for bit."""
+    from universal_speech_enhancement_amd.hip_engine import HipScoreEngine
+    x = torch.from_numpy(tnoise.complex_normal(31, "tx", (2, 1, 512, 128))) * 0.5
+    y = torch.from_numpy(tnoise.complex_normal(31, "ty", (2, 1, 512, 128))) * 0.5
+    t = torch.tensor([0.8, 0.1])
+    outs = []
+    for dev in (1, 0):                                       # the NON-default device first: it is the one an unset attribute would hit
+        with torch.cuda.device(dev):
+            e = HipScoreEngine(precision="bf16", device=dev)
+            e.load_state_dict(sd_np)
+            e.plan(2, 128)
+            outs.append(e.score(x.cuda(dev), y.cuda(dev), t.cuda(dev)).cpu())
+            torch.cuda.synchronize(dev)
+            e.close()
+    assert torch.isfinite(torch.view_as_real(outs[0])).all()
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_partial_totals_and_atomic_totals_give_the_same_score_bit_for_bit(engines, prec):
+    """GroupNorm statistics of the large maps: conv_v4 writes per-workgroup partial totals with plain stores (ConvArgs::stats_part) and
+    gn_finalize sums them, instead of 64-bit atomics on the item's totals (round 5).  Both are sums of the same fixed-point integers, so the
+    whole evaluation must agree BIT FOR BIT with the atomic form (use_set_option("stats_part", 0)); T' = 128 puts the 512 x 128 level
+    (65 536 px > the 128 x 160 inline threshold, 128 workgroups per image) on that path, B = 5 on two sub-batch streams (3 + 2)."""
+    from universal_speech_enhancement_amd.hip_engine import set_option
+    eng = engines[prec]
+    B, Tp = 5, 128
+    x = torch.from_numpy(tnoise.complex_normal(21, "px", (B, 1, 512, Tp))).cuda() * 0.5
+    y = torch.from_numpy(tnoise.complex_normal(21, "py", (B, 1, 512, Tp))).cuda() * 0.5
+    t = torch.tensor([0.9, 0.5, 0.2, 0.05, 0.7], device="cuda")
+    outs = {}
+    try:
+        for mode in (1, 0):
+            set_option("stats_part", mode)
+            eng.plan(B, Tp)
+            outs[mode] = eng.score(x, y, t).clone()
+    finally:
+        set_option("stats_part", 1)
+    assert torch.isfinite(torch.view_as_real(outs[1])).all()
+    assert torch.equal(outs[1], outs[0])
+
+
 def test_plans_and_graphs_of_recent_shapes_are_kept(engines):
     """A predict run over files of a few distinct lengths: 20 batches cycling through 5 padded lengths build 5 plans and capture 5
     graphs, not 20 (the plans of the most recently used shapes are parked with their graphs, use_engine.cpp: plan cache), and a

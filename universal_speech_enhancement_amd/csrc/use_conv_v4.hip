@@ -29,6 +29,15 @@ constexpr int V4_BN = 128;
 #define V4_ABL 0                    /* 4 no weight loads / stores, 8 no fragment reads, 16 no epilogue, 32 no chunk-0 staging in the prologue; */
                                     /* epilogue parts: 1024 no output stores, 2048 no LDS transposition, 4096 no statistics, 8192 no residual loads */
 #endif
+// Cache-policy bits (buffer instruction aux: 1 sc0, 2 nt, 16 sc1) of the output stores and the residual loads: both streams are touched
+// once per launch and are larger than the L2 (84-336 MB per launch on the conv_v4 maps).  Same-box end-to-end sweep, round 5
+// (profiles/r5_e2e_ab_cache_policy.txt): stores nt + sc1 and residual loads nt: -0.9 % per score evaluation; nt alone -0.5 %, sc0 alone +0.1 %.
+#ifndef V4_AUX_OUT
+#define V4_AUX_OUT 18
+#endif
+#ifndef V4_AUX_RES
+#define V4_AUX_RES 2
+#endif
 #ifndef V4_DEAD_LOADS               /* 1: the loads of the last K chunk's staging pass (results unused) go through an empty buffer descriptor */
 #define V4_DEAD_LOADS 1
 #endif
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         if (has_res) {
 #pragma unroll
             for (int q = 0; q < QN; ++q)
-                resv[q] = (V4_ABL & 8192) ? make_uint4(q, q, q, q) : __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff + row_b + (unsigned)q * pass_b, 0, 0));
+                resv[q] = (V4_ABL & 8192) ? make_uint4(q, q, q, q) : __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff + row_b + (unsigned)q * pass_b, 0, V4_AUX_RES));
         }
         if (!(V4_ABL & 2048)) {
 #pragma unroll
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
                 if (V4_ABL & 1024) asm volatile("" :: "v"(packed.x), "v"(packed.y), "v"(packed.z), "v"(packed.w));
                 else
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, packed), rs_out,
-                                                       voff + row_b + (unsigned)q * pass_b, 0, 0);
+                                                       voff + row_b + (unsigned)q * pass_b, 0, V4_AUX_OUT);
                 if (!(V4_ABL & 4096)) {
 #pragma unroll
                 for (int c = 0; c < CH; ++c) { st_s[c] += v[c]; st_q[c] = fmaf(v[c], v[c], st_q[c]); }

@@ -492,7 +492,7 @@ struct Fwd {
         // Large maps: the producer writes per-workgroup partial totals instead of queueing 640 atomics per item on each total; every consumer
         // of such a map goes through gn_coef (same threshold), which sums them.  (allocated in the dry run as well: the arena is sized by it)
         long long* part = (stats && g_stats_part && (long)a.H * a.W > g_gn_inline)
-                              ? (long long*)arena->alloc((size_t)B * conv_v4_tiles(a.H, a.W) * w.cout * 2 * sizeof(long long)) : nullptr;
+                              ? (long long*)arena->alloc((size_t)B * std::max(conv_v4_tiles(a.H, a.W), 256) * w.cout * 2 * sizeof(long long)) : nullptr;
         if (h->dry) return o;
         ConvArgs p{};
         p.src0 = a.p; p.C0 = a.C; p.src1 = a2 ? a2->p : nullptr; p.C1 = a2 ? a2->C : 0; p.in_dtype = a.dtype;
@@ -513,7 +513,7 @@ struct Fwd {
         p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
         p.B = B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
         const bool main_variant = conv_v4_eligible(p);        // the dominant kernel (conv_v4_kernel, large maps)
-        if (part && main_variant) { p.stats_part = part; p.stats = nullptr; o.part = part; o.ntiles = conv_v4_tiles(a.H, a.W); }
+        if (const int nparts = part ? conv_stats_parts(p) : 0) { p.stats_part = part; p.stats = nullptr; o.part = part; o.ntiles = nparts; }
         if (h->profile && (main_variant || (h->profile_all && conv_v2_eligible(p)))) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, s);

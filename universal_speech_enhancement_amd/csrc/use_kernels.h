@@ -33,6 +33,7 @@ constexpr int TILE_H = 8;    // conv output tile: 8 x 16 pixels = 128 GEMM rows
 constexpr int TILE_W = 16;
 
 inline int tiles_per_image(int H, int W) { return ((H + TILE_H - 1) / TILE_H) * ((W + TILE_W - 1) / TILE_W); }
+inline int conv_in_split_wgs(int H, int W) { const int nt = tiles_per_image(H, W), tpw = (nt + 255) / 256; return (nt + tpw - 1) / tpw; }   // conv_in_split_kernel: <= 256 workgroups per item
 inline int conv_v2_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 15) / 16); }   // conv_v2_kernel: 16x16 tiles
 
 // Implicit-GEMM convolution (3x3 pad 1, or 1x1) with fused prologue / epilogue.
@@ -77,6 +78,7 @@ struct ConvArgs {
     unsigned long long* trace;   // optional: s_memtime stamps of workgroup 0 (kernel bring-up), else null
 };
 void launch_conv(const ConvArgs& a, hipStream_t s);
+int conv_stats_parts(const ConvArgs& a);                // partial totals per (item, channel) this launch would write (ConvArgs::stats_part), or 0
 // software-pipelined variant for large maps (use_conv_v2.hip); launch_conv dispatches to it when eligible
 bool conv_v2_eligible(const ConvArgs& a);
 void launch_conv_v2(const ConvArgs& a, hipStream_t s);

@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) void conv_in_split_kernel(ConvArgs p, int tile
         }
         __syncthreads();                                     // every wave is done with this tile's halo
     }
-    if (p.stats) {
+    if (p.stats || p.stats_part) {
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
@@ -869,7 +869,12 @@ __global__ __launch_bounds__(256) void conv_in_split_kernel(ConvArgs p, int tile
 #pragma unroll
             for (int w = 0; w < 4; ++w) { sm += s_red[(w * 128 + tid) * 2]; q += s_red[(w * 128 + tid) * 2 + 1]; }
             const int co = n0 + tid;
-            if (co < p.Cout) gn_accumulate(p.stats + ((size_t)b * p.Cout + co) * 2, sm, q);
+            if (co < p.Cout) {
+                if (p.stats_part) {                          // this workgroup's partial totals (ConvArgs::stats_part): no queue on the item's 256 totals
+                    long long* d = p.stats_part + (((size_t)b * gridDim.x + blockIdx.x) * p.Cout + co) * 2;
+                    *reinterpret_cast<longlong2*>(d) = make_longlong2(__float2ll_rn(sm * GN_SUM_SCALE), __float2ll_rn(q * GN_SQ_SCALE));
+                } else gn_accumulate(p.stats + ((size_t)b * p.Cout + co) * 2, sm, q);
+            }
         }
     }
 }
@@ -884,6 +889,15 @@ static void conv_launch_t(const ConvArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((conv_kernel<TIN, TOUT, CK, BN, WM, WN>), grid, dim3(256), 0, s, a);
 }
 
+// Workgroups that would each write one partial total per output channel for this launch (ConvArgs::stats_part), 0 if the kernel the
+// dispatch below picks only knows the atomic form.  Mirrors launch_conv's order.
+int conv_stats_parts(const ConvArgs& a) {
+    if (conv_sk_eligible(a)) return 0;
+    if (conv_v4_eligible(a)) return conv_v4_tiles(a.H, a.W);
+    if (conv_v2_eligible(a)) return 0;
+    if (!pyr_conv_eligible(a) && conv_in_eligible(a) && a.wb && a.out_dtype != DT_F32) return conv_in_split_wgs(a.H, a.W);
+    return 0;
+}
 void launch_conv(const ConvArgs& a, hipStream_t s) {
 #ifdef USE_HIP_SKIPDBG   // timing-only bring-up build: drop the convolutions of maps with lo <= H*W <= hi pixels (USE_HIP_SKIP="lo:hi")
     {
@@ -934,7 +948,7 @@ void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
     if (conv_in_eligible(a)) {
         dim3 grid(tiles_per_image(a.H, a.W), (a.Cout + 127) / 128, a.B);
         const int ntiles = tiles_per_image(a.H, a.W), tpw = (ntiles + 255) / 256;       // <= 256 workgroups per item
-        dim3 grid_s((ntiles + tpw - 1) / tpw, (a.Cout + 127) / 128, a.B);
+        dim3 grid_s(conv_in_split_wgs(a.H, a.W), (a.Cout + 127) / 128, a.B);
         if (a.out_dtype == DT_BF16)     { if (a.wb) hipLaunchKernelGGL((conv_in_split_kernel<__bf16>), grid_s, dim3(256), 0, s, a, tpw);
                                           else      hipLaunchKernelGGL((conv_in_kernel<__bf16>), grid, dim3(256), 0, s, a); }
         else if (a.out_dtype == DT_F16) { if (a.wb) hipLaunchKernelGGL((conv_in_split_kernel<_Float16>), grid_s, dim3(256), 0, s, a, tpw);
