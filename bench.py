@@ -249,7 +249,8 @@ def main():
                 return
             stop_probe.wait(0.5)
     pt = None
-    if rank == 0 and not a.no_power_probe:
+    torch.cuda.device_count()                                   # (cached before the sampling thread initialises amdsmi: torch's own count goes through amdsmi too)
+    if rank == 0 and not a.no_power_probe and a.steps:
         pt = threading.Thread(target=power_thread, daemon=True); pt.start()
     barrier()
     t0 = time.perf_counter()

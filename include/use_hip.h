@@ -65,7 +65,10 @@ typedef struct use_sampler_config {
 /* Process-wide tuning knobs (no reference counterpart).  "subbatch" (default 2): batches of >= 4 items are evaluated as
  * two halves on two streams, staggered so that the small-map kernels of one half run beside the large convolutions of
  * the other; items never interact inside the network, so results are identical to subbatch = 0 (read at use_plan).  "conv_v4_min_blocks": smallest per-image grid (workgroups) the
- * wide-tile convolution kernel is selected for, default 128; results do not depend on it beyond rounding order. */
+ * wide-tile convolution kernel is selected for, default 80; results do not depend on it beyond rounding order.  "stats_part" (default 1): on maps
+ * above "gn_inline" pixels (default 128 x 160) the convolutions write per-workgroup GroupNorm partial totals with plain stores and the
+ * finalisation sums them, instead of 64-bit atomics on the item's totals - integer sums either way: bit-identical results (read at use_plan).
+ * Others: "stagger_level", "gn_inline", "plan_cache", "attn_fused", "pyr_pipe", "conv_sk_max_px", "wgrad_mfma16", "wgrad_blocks" (INTEGRATION.md). */
 int use_set_option(const char* name, long long value);
 const char* use_last_error(void);
 const char* use_version(void);
