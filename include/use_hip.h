@@ -62,9 +62,9 @@ typedef struct use_sampler_config {
     int use_graph;         /* 1: capture the whole loop in a hipGraph and replay it                    */
 } use_sampler_config;
 
-/* Process-wide tuning knobs (no reference counterpart).  "subbatch" (default 2): batches of >= 4 items are evaluated as
- * two halves on two streams, staggered so that the small-map kernels of one half run beside the large convolutions of
- * the other; items never interact inside the network, so results are identical to subbatch = 0 (read at use_plan).  "conv_v4_min_blocks": smallest per-image grid (workgroups) the
+/* Process-wide tuning knobs (no reference counterpart).  "subbatch" (default -1 = by batch size: three sub-batches for 6-11 items, else two; round 5: batch 8 as 3 + 3 + 2 is 1.6 % faster than 4 + 4): batches of >= 4 items are evaluated as
+ * sub-batches (>= 2 items each) on separate streams, staggered so that the small-map kernels of one run beside the large convolutions of
+ * the others; items never interact inside the network, so results are identical to subbatch = 0 (read at use_plan).  "conv_v4_min_blocks": smallest per-image grid (workgroups) the
  * wide-tile convolution kernel is selected for, default 80; results do not depend on it beyond rounding order.  "stats_part" (default 1): on maps
  * above "gn_inline" pixels (default 128 x 160) the convolutions write per-workgroup GroupNorm partial totals with plain stores and the
  * finalisation sums them, instead of 64-bit atomics on the item's totals - integer sums either way: bit-identical results (read at use_plan).

@@ -20,4 +20,4 @@ for prec in ("bf16", "fp32"):
             else: outs[k] = o.clone()
         e.close()
     print(prec, "ok")
-set_option("subbatch", 2)
+set_option("subbatch", -1)

@@ -311,7 +311,7 @@ def test_use_hip_opts_environment_is_applied_at_load(monkeypatch):
     from universal_speech_enhancement_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
         pytest.skip("library not built")
-    monkeypatch.setenv("USE_HIP_OPTS", "subbatch=2,plan_cache=4")
+    monkeypatch.setenv("USE_HIP_OPTS", "subbatch=3,plan_cache=4")
     monkeypatch.setattr(_lib, "_lib", None)
     assert _lib.lib() is not None
     for bad in ("no_such_option=1", "subbatch", "subbatch=two"):          # unknown name, no value, no integer: every call fails, not only the first

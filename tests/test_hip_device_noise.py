@@ -6,7 +6,7 @@ recorded noise; here the device stream itself is pinned:
 
   (a) use_fill_noise(seed, d) exposes draw d of that stream, and use_sample(noise = [fill(seed, d) for d]) must reproduce
       use_sample(noise = NULL, seed) BIT FOR BIT - fp32 and bf16, hipGraph replay and eager launches, Langevin (whose norms kernel
-      and update kernel must see the SAME z) and ALD, on B = 8 evaluated as 4 + 4 items on two streams;
+      and update kernel must see the SAME z) and ALD, on B = 8 evaluated as 3 + 3 + 2 items on three streams;
   (b) the 61 draws of the benchmark configuration (N = 30, Langevin x 1) are fresh streams: every pair of draws and every pair of batch
       items is uncorrelated, and every draw has the moments of a standard complex normal;
   (c) the replayed run then matches the CPU oracle fed the same recorded draws (fp32, <= 2e-3 per item), so the device-noise run IS
@@ -108,7 +108,7 @@ def test_benchmark_configuration_draws_are_fresh_independent_standard_normals(en
     for lag in (2, n // B):
         r = (Z[:, :-lag] * Z[:, lag:]).mean(1)
         assert float(r.abs().max()) < bound_d, (lag, float(r.abs().max()))
-    # every pair of batch items (and with them the two sub-batches 0-3 / 4-7), over all draws: 61 * 65 536 reals per item
+    # every pair of batch items (and with them the sub-batches 0-2 / 3-5 / 6-7), over all draws: 61 * 65 536 reals per item
     per = D.reshape(nd, B, -1).permute(1, 0, 2).reshape(B, -1)
     Zi = (per - per.mean(1, keepdim=True)) / per.std(1, keepdim=True)
     Ci = (Zi @ Zi.T) / Zi.shape[1]

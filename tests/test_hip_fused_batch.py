@@ -1,8 +1,8 @@
 """GPU parity of the code path bench.py times: the fused sampler (use_sample) with the Langevin corrector on batches that
-are evaluated as two sub-batches on two streams (B >= 4), against the CPU oracle.
+are evaluated as sub-batches on separate streams (B >= 4: two for B = 4-5, three from B = 6), against the CPU oracle.
 
 LangevinCorrector takes its step size from norms averaged over the WHOLE batch (reference
-sgmse/sampling/correctors.py:45-63; loop order sampling/__init__.py:64-68), so the two sub-batch streams must be joined
+sgmse/sampling/correctors.py:45-63; loop order sampling/__init__.py:64-68), so the sub-batch streams must be joined
 before the norms are reduced.  Items carry distinct gains so that their norms differ by an order of magnitude: a step size
 formed from one sub-batch alone would be off by far more than the tolerance.
 
@@ -67,7 +67,7 @@ def _inputs_and_oracle(sd_np, B):
 
 @pytest.mark.parametrize("B", [5, 8])
 def test_fused_langevin_on_split_batches_matches_the_oracle_fp32(sd_np, B):
-    """B = 5 is evaluated as 3 + 2 items, B = 8 as 4 + 4 (the benchmarked split); hipGraph replay and eager launches."""
+    """B = 5 is evaluated as 3 + 2 items, B = 8 as 3 + 3 + 2 (the benchmarked split: three sub-batch streams since round 5); hipGraph replay and eager launches."""
     wav, draws, ref, spec = _inputs_and_oracle(sd_np, B)
     outs = {}
     for use_graph in (True, False):

@@ -194,19 +194,19 @@ def test_odd_widths_at_the_bottom_of_the_unet_fp32(engines, sd_np):
 def test_subbatch_pipelining_is_a_pure_rescheduling(sd_np):
     """Batches of >= 4 items run as staggered sub-batches on separate streams: bit-identical to the unsplit evaluation."""
     from universal_speech_enhancement_amd.hip_engine import HipScoreEngine, set_option
-    x = torch.from_numpy(tnoise.complex_normal(5, "x", (5, 1, 512, 64))).cuda() * 0.5
-    y = torch.from_numpy(tnoise.complex_normal(5, "y", (5, 1, 512, 64))).cuda() * 0.5
-    t = torch.linspace(0.9, 0.1, 5).cuda()
+    x = torch.from_numpy(tnoise.complex_normal(5, "x", (7, 1, 512, 64))).cuda() * 0.5
+    y = torch.from_numpy(tnoise.complex_normal(5, "y", (7, 1, 512, 64))).cuda() * 0.5
+    t = torch.linspace(0.9, 0.1, 7).cuda()
     outs = []
     try:
-        for n in (1, 2, 4):
+        for n in (1, 2, 3):                                  # 7 items: unsplit, 4 + 3, 3 + 2 + 2 (three streams: the default since round 5)
             set_option("subbatch", n)
             e = HipScoreEngine(precision="bf16")
             e.load_state_dict(sd_np)
             outs.append(e.score(x, y, t).clone())
             e.close()
     finally:
-        set_option("subbatch", 2)
+        set_option("subbatch", -1)
     assert torch.isfinite(torch.view_as_real(outs[0])).all()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
@@ -544,7 +544,7 @@ def test_minibatch_sampler_and_enhance(sd_np):
 
 def test_cfg2_shape_score_fp32_matches_oracle(sd_np):
     """BASELINE configs[1] map sizes against the CPU oracle: one fp32 score evaluation at [B, ., 512, 640] -- conv_v4 at its real
-    grid (20 tiles per row), the 80-token attention, and (B = 8) the 4+4 sub-batch split.  Items 0 and 5 are distinct
+    grid (20 tiles per row), the 80-token attention, and (B = 8) the 3+3+2 sub-batch split.  Items 0 and 5 are distinct
     inputs at different t (one per sub-batch); the other six items are copies of them, so the oracle runs on two items."""
     from universal_speech_enhancement_amd.hip_engine import HipScoreEngine
     eng = HipScoreEngine(precision="fp32")

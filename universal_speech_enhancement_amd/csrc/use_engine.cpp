@@ -84,7 +84,7 @@ struct PyrW { GNW gn; ConvW conv; };
 
 struct Expected { std::string name; std::vector<int64_t> shape; };
 
-constexpr int MAX_SUB = 4;                       // sub-batches of the pipelined evaluation (run_score)
+constexpr int MAX_SUB = 8;                       // sub-batches of the pipelined evaluation (run_score)
 
 struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, dtype = DT_F32; long long* stats = nullptr;     // stats: [B][C][2] fixed-point totals
              long long* part = nullptr; int ntiles = 0; };   // or (large maps, conv_v4 producers) [B][ntiles][C][2] per-workgroup partial totals (ConvArgs::stats_part)
@@ -140,14 +140,14 @@ struct use_handle {
     float* ts_dev = nullptr; float* temb_table = nullptr; float* silu_table = nullptr;
     float2* noise_copy = nullptr; size_t noise_copy_bytes = 0;
     hipStream_t cap_stream = nullptr;
-    // sub-batch pipelining (see run_score): the batch is evaluated as two halves on two streams, the second started when
+    // sub-batch pipelining (see run_score): the batch is evaluated as up to MAX_SUB sub-batches (default three) on as many streams, the second started when
     // the first reaches its small feature maps, so that one half's latency-bound kernels hide behind the other's large ones
-    int nsub = 1, sub_B[MAX_SUB] = {0, 0, 0, 0};  // sub-batch sizes (nsub = 1: not split)
+    int nsub = 1, sub_B[MAX_SUB] = {};  // sub-batch sizes (nsub = 1: not split)
     Arena sub_arena[MAX_SUB];                    // workspaces of sub-batches 1.. (inside the same allocation as `arena`)
     Arena st_arena[MAX_SUB];                     // per sub-batch: the GroupNorm totals of all its activations, contiguous (one memset per evaluation)
-    hipStream_t aux_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_stagger[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr},
-               ev_join[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux_stream[MAX_SUB] = {};
+    hipEvent_t ev_fork = nullptr, ev_stagger[MAX_SUB] = {},
+               ev_join[MAX_SUB] = {};
     int debug_B = 0;
     std::vector<hipGraphExec_t> graph_exec[2];           // [0]: device RNG, [1]: injected noise; one graph per segment of steps
     hipGraphExec_t score_graph = nullptr;
@@ -427,7 +427,9 @@ static int pack_all(use_handle* h, char* blob) {
 // ---------------------------------------------------------------------------------------------------------
 // forward pass (one score-network evaluation)
 // ---------------------------------------------------------------------------------------------------------
-static int g_subbatch = 2;                       // use_set_option("subbatch", n): sub-batches per evaluation (0/1: off)
+static int g_subbatch_min_items = 2;              // use_set_option("subbatch_min_items", n): no sub-batch smaller than n items
+static int g_subbatch_rev = 0;                   // use_set_option("subbatch_rev", 1): the smaller sub-batches first (B = 8 in three: 2 + 3 + 3)
+static int g_subbatch = -1;                      // use_set_option("subbatch", n): sub-batches per evaluation (0 / 1: off; -1: by batch size, below)
 // GroupNorm finalisation inside the consuming conv (no launch) for maps of at most g_gn_inline pixels per item, a separate
 // finalize launch above: on the large maps thousands of workgroups would each redo the finalisation (measured slower), on the
 // small, latency-bound maps the saved launch is what counts.  use_set_option("gn_inline", pixels); 0: never inline
@@ -922,6 +924,8 @@ int use_set_option(const char* name, long long value) {
     ++g_opt_gen;                                               // plans built under the previous options are not reused
     if (!strcmp(name, "attn_fused")) { g_attn_fused = (int)value; return USE_OK; }
     if (!strcmp(name, "plan_cache")) { g_plan_cache = (int)std::max(0LL, std::min(16LL, value)); return USE_OK; }   // parked plans per handle
+    if (!strcmp(name, "subbatch_rev")) { g_subbatch_rev = (int)value; return USE_OK; }
+    if (!strcmp(name, "subbatch_min_items")) { g_subbatch_min_items = (int)std::max(1LL, value); return USE_OK; }
     if (!strcmp(name, "subbatch")) { g_subbatch = (int)value; return USE_OK; }          // takes effect at the next use_plan
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
     if (!strcmp(name, "stats_part")) { g_stats_part = (int)value; return USE_OK; }                  // takes effect at the next use_plan
@@ -1147,14 +1151,20 @@ int use_plan(use_handle* h, int B, int Tpad) {
     h->opt_gen_at_plan = g_opt_gen;
     h->B = B; h->T = Tpad; h->sampler_set = false;
     // sub-batch pipelining (run_score): `subbatch` sub-batches of at least 2 items each
-    h->nsub = std::max(1, std::min(std::min(g_subbatch, MAX_SUB), B / 2));
+    // How many sub-batches: a question of grid quantisation on the 256 CUs (same-box sweeps, profiles/r5_e2e_ab_subbatch_sweep.txt).  The 3x3
+    // convolutions of the 256 x 320 / 128 x 160 maps launch 160 / 80 workgroups per item: sub-batches of 4 items leave 2.5 / 1.25 rounds (83 % /
+    // 62 % of the last round's CUs busy), of 3 items 1.9 / 0.94 - batch 8 runs 1.6 % faster as 3 + 3 + 2 than as 4 + 4 (bf16 and fp16), five or
+    // more streams 12-17 % slower; batch 16 is fastest as 8 + 8 (5 / 2.5 rounds; 6 + 5 + 5: +0.7 %).
+    const int want = g_subbatch >= 0 ? g_subbatch : (B >= 6 && B <= 11) ? 3 : 2;
+    h->nsub = std::max(1, std::min(std::min(want, MAX_SUB), B / std::max(1, g_subbatch_min_items)));
     for (int i = 0; i < MAX_SUB; ++i) h->sub_B[i] = i < h->nsub ? B / h->nsub + (i < B % h->nsub ? 1 : 0) : 0;
+    if (g_subbatch_rev) std::reverse(h->sub_B, h->sub_B + h->nsub);
     // dry runs to size the activation arenas (one per sub-batch, carved from one allocation).  The allocation itself is kept
     // when it is large enough: a predict run over files of different lengths re-plans for almost every batch
     char* old_base = h->arena.base;
     h->arena = Arena{};
     h->dry = true;
-    size_t caps[MAX_SUB] = {0, 0, 0, 0}, stcaps[MAX_SUB] = {0, 0, 0, 0}, total = 0;
+    size_t caps[MAX_SUB] = {}, stcaps[MAX_SUB] = {}, total = 0;
     for (int i = 0; i < h->nsub; ++i) {
         Arena& ar = i ? h->sub_arena[i] : h->arena;
         ar = Arena{}; h->st_arena[i] = Arena{};
