@@ -35,6 +35,9 @@ constexpr int V4_BN = 128;
 #ifndef V4_AUX_OUT
 #define V4_AUX_OUT 18
 #endif
+#ifndef V4_AUX_IN
+#define V4_AUX_IN 0
+#endif
 #ifndef V4_AUX_RES
 #define V4_AUX_RES 2
 #endif
@@ -170,6 +173,10 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, live ? 0x7fffffff : 0, 0x00020000);
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
     };
+    auto buf_ld_in = [&](const void* base, unsigned voff, unsigned soff, int live) -> uint4 {    // halo pieces (cache policy V4_AUX_IN)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, live ? 0x7fffffff : 0, 0x00020000);
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, V4_AUX_IN));
+    };
     auto src_ld0 = [&](int chunk, int pixoff, int live = 1) -> uint4 {
         const int c_glob = chunk * CK;
         const TIN* src; int Cs, c_loc;
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         else               { src = (const TIN*)p.src1; Cs = p.C1; c_loc = c_glob - p.C0; }
         const unsigned voff = (unsigned)pixoff * (unsigned)(Cs * (int)sizeof(TIN)) + (unsigned)(part * 16);
         // per-item buffer base: the 32-bit offsets only have to span one image (any batch size, < 2 GB per image tensor)
-        return buf_ld(src + (size_t)b * p.H * p.W * Cs, voff, (unsigned)(c_loc * (int)sizeof(TIN)), live);
+        return buf_ld_in(src + (size_t)b * p.H * p.W * Cs, voff, (unsigned)(c_loc * (int)sizeof(TIN)), live);
     };
     // ---- segment-1 (shortcut) pieces: the 16x32 centre pixels, 4 per thread, raw ----------------------------------------
     auto load_piece1 = [&](int chunk2, int q, uint4& raw) -> unsigned {

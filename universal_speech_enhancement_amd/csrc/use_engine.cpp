@@ -428,7 +428,6 @@ static int pack_all(use_handle* h, char* blob) {
 // forward pass (one score-network evaluation)
 // ---------------------------------------------------------------------------------------------------------
 static int g_subbatch_min_items = 2;              // use_set_option("subbatch_min_items", n): no sub-batch smaller than n items
-static int g_subbatch_rev = 0;                   // use_set_option("subbatch_rev", 1): the smaller sub-batches first (B = 8 in three: 2 + 3 + 3)
 static int g_subbatch = -1;                      // use_set_option("subbatch", n): sub-batches per evaluation (0 / 1: off; -1: by batch size, below)
 // GroupNorm finalisation inside the consuming conv (no launch) for maps of at most g_gn_inline pixels per item, a separate
 // finalize launch above: on the large maps thousands of workgroups would each redo the finalisation (measured slower), on the
@@ -451,6 +450,7 @@ struct Fwd {
     Arena* st_arena = nullptr;                    // its GroupNorm-totals region
     bool primary = true;                          // the first sub-batch owns the FLOP count and the debug tensors
     hipEvent_t ev_stagger = nullptr;              // recorded when the large maps of the down path are done (or null)
+    int stagger_level = 2;                        // ... i.e. after this level of the down path
     template <typename T> const T* W(size_t off) const { return (const T*)(h->blob + off); }
 
     Act new_act(int C, int H, int Wd, int dtype, bool stats) {
@@ -657,7 +657,7 @@ struct Fwd {
         size_t ri = 0, ci = 0;
         for (int lvl = 0; lvl < L; ++lvl) {
             for (int k = 0; k < nrb; ++k) hs.push_back(resblock(hs.back(), nullptr, H->res[ri++]));
-            if (lvl == std::min(g_stagger_level, L - 1) && ev_stagger && !H->dry) (void)hipEventRecord(ev_stagger, s);   // small maps follow
+            if (lvl == std::min(stagger_level, L - 1) && ev_stagger && !H->dry) (void)hipEventRecord(ev_stagger, s);   // small maps follow
             if (lvl != L - 1) {
                 Act nip = new_act(pcp, ipyr.H / 2, ipyr.W / 2, DT_F32, false);        // pyramid_downsample
                 if (!H->dry) launch_fir_down2(ipyr.p, DT_F32, nullptr, 0, nullptr, nip.p, B, ipyr.H, ipyr.W, pcp, s);
@@ -748,7 +748,7 @@ static void run_score(use_handle* h, const float2* x, const float2* y, const flo
         Fwd f{h, si, tembias ? tembias + (size_t)b0 * temb_bstride : nullptr, temb_bstride,
               t ? t + (size_t)b0 * t_stride : nullptr, t_stride};
         f.B = h->sub_B[i]; f.arena = i ? &h->sub_arena[i] : &h->arena; f.st_arena = &h->st_arena[i]; f.primary = i == 0;
-        if (overlap && i + 1 < h->nsub) f.ev_stagger = h->ev_stagger[i];
+        if (overlap && i + 1 < h->nsub) { f.ev_stagger = h->ev_stagger[i]; f.stagger_level = g_stagger_level; }
         Act pyr = f.run(h->x4 + (size_t)b0 * n_per_b * pcp);
         launch_score_out((const float*)pyr.p, pcp, t ? t + (size_t)b0 * t_stride : nullptr, t_stride, outw, outb,
                          out + (size_t)b0 * n_per_b, h->sub_B[i], n_per_b, sign, si);
@@ -924,7 +924,6 @@ int use_set_option(const char* name, long long value) {
     ++g_opt_gen;                                               // plans built under the previous options are not reused
     if (!strcmp(name, "attn_fused")) { g_attn_fused = (int)value; return USE_OK; }
     if (!strcmp(name, "plan_cache")) { g_plan_cache = (int)std::max(0LL, std::min(16LL, value)); return USE_OK; }   // parked plans per handle
-    if (!strcmp(name, "subbatch_rev")) { g_subbatch_rev = (int)value; return USE_OK; }
     if (!strcmp(name, "subbatch_min_items")) { g_subbatch_min_items = (int)std::max(1LL, value); return USE_OK; }
     if (!strcmp(name, "subbatch")) { g_subbatch = (int)value; return USE_OK; }          // takes effect at the next use_plan
     if (!strcmp(name, "stagger_level")) { g_stagger_level = (int)value; return USE_OK; }
@@ -1158,7 +1157,6 @@ int use_plan(use_handle* h, int B, int Tpad) {
     const int want = g_subbatch >= 0 ? g_subbatch : (B >= 6 && B <= 11) ? 3 : 2;
     h->nsub = std::max(1, std::min(std::min(want, MAX_SUB), B / std::max(1, g_subbatch_min_items)));
     for (int i = 0; i < MAX_SUB; ++i) h->sub_B[i] = i < h->nsub ? B / h->nsub + (i < B % h->nsub ? 1 : 0) : 0;
-    if (g_subbatch_rev) std::reverse(h->sub_B, h->sub_B + h->nsub);
     // dry runs to size the activation arenas (one per sub-batch, carved from one allocation).  The allocation itself is kept
     // when it is large enough: a predict run over files of different lengths re-plans for almost every batch
     char* old_base = h->arena.base;
