@@ -341,7 +341,7 @@ def main():
     peak = PEAK_FP32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS      # bf16 and fp16 MFMA share the dense peak
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12
     # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), which cannot be
-    # collected from inside the timed process: the committed summary of scripts/run_pmc.sh on this workload is quoted.
+    # collected from inside the timed process: the committed summary of `scripts/profile.sh pmc <tag>` + `scripts/pmc_to_json.py` on this workload is quoted.
     traffic, traffic_src = None, None
     if a.precision == "bf16" and (B, Tp) == (8, 640):   # the PMC passes were collected on exactly this workload
         import glob

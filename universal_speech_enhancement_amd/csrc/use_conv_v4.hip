@@ -408,7 +408,9 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
 #define V4_BAR() { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
     // rendezvous at the end of an MFMA phase: the only LDS operation a wave may have in flight there is the store of the piece it has
     // just transformed, which nobody reads before the next chunk (several full barriers later) - no lgkmcnt wait in front of it
-#define V4_BAR_M() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+// (asm with a memory clobber, not __builtin_amdgcn_s_barrier(): the builtin is IntrNoMem, so nothing at IR level would keep LDS accesses on
+// their side of it - ADVICE r4; the generated code is instruction-for-instruction the same, checked in round 5)
+#define V4_BAR_M() { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
     V4_STAMP(2)
     V4_BAR();
     V4_STAMP(3)
@@ -639,8 +641,7 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         }
         // (not __syncthreads(): its release fence waits for the acknowledgement of this wave's 16 output stores - 2-3 k cycles in which
         // the reduction and the atomics below can already run; only the LDS writes above have to have landed)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (tid < BN) {
             float s = 0.f, q = 0.f;
 #pragma unroll
