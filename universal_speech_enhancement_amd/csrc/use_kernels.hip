@@ -1058,6 +1058,21 @@ void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int 
 // ---------------------------------------------------------------------------------------------------------
 // FIR x2 resampling, separable [1,3,3,1]: up -> polyphase (0.25, 0.75) pairs; down -> [1,3,3,1]/8 per axis
 // ---------------------------------------------------------------------------------------------------------
+// 16-byte store with the nontemporal cache policy: the resamplers' outputs are touched once and, on the large maps, larger than the L2
+// (same-box end-to-end A/B, round 5: -0.25 % per score evaluation, profiles/r5_e2e_ab_cache_policy.txt; -DFIR_NT=0 for the plain store)
+#ifndef FIR_NT
+#define FIR_NT 1
+#endif
+template <typename T, int N>
+DEVI void store16_nt(T* p, const float (&v)[N]) {
+    const uint4 u = Vec16<T>::pack(v);
+#if FIR_NT
+    __builtin_nontemporal_store(u.x, reinterpret_cast<unsigned*>(p)); __builtin_nontemporal_store(u.y, reinterpret_cast<unsigned*>(p) + 1);
+    __builtin_nontemporal_store(u.z, reinterpret_cast<unsigned*>(p) + 2); __builtin_nontemporal_store(u.w, reinterpret_cast<unsigned*>(p) + 3);
+#else
+    *reinterpret_cast<uint4*>(p) = u;
+#endif
+}
 template <typename T, bool UP>
 __global__ __launch_bounds__(256) void fir_kernel(const T* __restrict__ src, const float* __restrict__ coef, int act,
                                                   T* __restrict__ out_act, T* __restrict__ out_raw, int B, int H,
@@ -1177,8 +1192,8 @@ __global__ __launch_bounds__(256) void fir_up_blk_kernel(const T* __restrict__ s
                     oa[k] = wy0 * (wx0 * xa[0][0][k] + wx1 * xa[0][1][k]) + wy1 * (wx0 * xa[1][0][k] + wx1 * xa[1][1][k]);
                 }
                 const size_t o = ((size_t)(b * 2 * H + oy) * (2 * W) + ox) * C + c;
-                if (out_raw) Vec16<T>::store(out_raw + o, orr);
-                if (want_act) Vec16<T>::store(out_act + o, oa);
+                if (out_raw) store16_nt(out_raw + o, orr);
+                if (want_act) store16_nt(out_act + o, oa);
             }
     }
 }
@@ -1277,8 +1292,8 @@ __global__ __launch_bounds__(256) void fir_down_blk_kernel(const T* __restrict__
                 const int oy = 2 * by + i, ox = 2 * bx + j;
                 if (oy >= OH || ox >= OW) continue;
                 const size_t o = ((size_t)(b * OH + oy) * OW + ox) * C + c;
-                if (out_raw) Vec16<T>::store(out_raw + o, ar[i][j]);
-                if (want_act) Vec16<T>::store(out_act + o, aa[i][j]);
+                if (out_raw) store16_nt(out_raw + o, ar[i][j]);
+                if (want_act) store16_nt(out_act + o, aa[i][j]);
             }
     }
 }
