@@ -119,6 +119,31 @@ def test_fir_resampling_matches_the_reference(golden_dir, dt, tol):
     assert float(up.float()[..., 5:].abs().max()) == 0.0             # padding channels stay zero
 
 
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 16, 12, 16), (1, 64, 40, 128), (3, 48, 34, 32), (2, 24, 20, 8)])
+def test_fir_down_strip_walk_equals_the_block_form(dt, shape):
+    """The res-block down-sampler in its hot configuration (affine + SiLU, activated and raw output, 16-bit storage) runs as a strip walk
+    (fir_down_strip_kernel, round 5: each input activated once per thread, OH % 8 == 0) - its taps accumulate in the block kernel's order, so the two
+    forms must agree BIT FOR BIT; the block form is the one pinned against the reference's resampler (test above) and res-block goldens.
+    Shapes: borders in both directions, odd output widths, one 8-row strip and several, OH % 8 != 0 (falls back to the block form)."""
+    from universal_speech_enhancement_amd.hip_engine import set_option
+    B, H, W, Cc = shape
+    g = torch.Generator().manual_seed(H * 131 + W)
+    x = (torch.randn(B, H, W, Cc, generator=g) * 1.5).to(torch.bfloat16 if dt == 1 else torch.float16).cuda()
+    coef = torch.stack([0.5 + torch.rand(B, Cc, generator=g), torch.randn(B, Cc, generator=g) * 0.3], dim=-1).cuda().contiguous()
+    outs = {}
+    try:
+        for mode in (1, 8, 4, 0):                            # by grid size / 8-row strips / 4-row strips / block form
+            set_option("fir_strip", mode)
+            outs[mode] = _fir(x, dt, coef, 1, False)
+    finally:
+        set_option("fir_strip", 1)
+    for k in (0, 1):
+        assert torch.isfinite(outs[0][k].float()).all()
+        for mode in (1, 8, 4):
+            assert torch.equal(outs[mode][k], outs[0][k]), (shape, dt, k, mode)
+
+
 def _run_resblock(g, dt, variant, up=False, down=False, split=None):
     """One ResnetBlockBigGANpp through the HIP operators; split = channels of the first of two concatenated sources."""
     x, temb = torch.from_numpy(g["x"]), torch.from_numpy(g["temb"])

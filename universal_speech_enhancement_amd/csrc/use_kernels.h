@@ -106,6 +106,7 @@ void launch_gn_finalize(const long long* st0, int C0, const long long* st1, int 
 // out_act (nullable) = FIR(act(a*x+b)), out_raw (nullable) = FIR(x).
 void launch_fir_up2(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
                     int H, int W, int C, hipStream_t s);
+void fir_set_strip(int on);                             // down-sampler as a strip walk (default on)
 void launch_fir_down2(const void* src, int dtype, const float* coef, int act, void* out_act, void* out_raw, int B,
                       int H, int W, int C, hipStream_t s);
 
