@@ -244,6 +244,33 @@ def test_input_convolution_16bit_modes_match_the_oracle(golden_dir, engines, sd_
     assert float((err - (ulp * want.abs() + 2e-4)).max()) <= 0, float(err.max())
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_input_convolution_walk_length_changes_nothing_but_the_statistics_order(engines, prec):
+    """conv_in_split_kernel walks `tiles / conv_in_wgs` tiles per workgroup with the next tile's halo prefetched behind the current tile's
+    MFMAs and stores (round 5).  The walk length must not change a single stored value (h_in bit-identical for 512 / 256 / 37 / 1 workgroups
+    per item: walks of 1, 2, 14 and all 512 tiles at T' = 128), and the score may move only by the summation order of the GroupNorm totals."""
+    from universal_speech_enhancement_amd.hip_engine import set_option
+    eng = engines[prec]
+    B, Tp = 3, 128
+    x = torch.from_numpy(tnoise.complex_normal(5, "cx", (B, 1, 512, Tp))).cuda() * 0.7
+    y = torch.from_numpy(tnoise.complex_normal(5, "cy", (B, 1, 512, Tp))).cuda() * 0.7
+    t = torch.tensor([0.8, 0.3, 0.05], device="cuda")
+    h, sc = {}, {}
+    try:
+        for wgs in (512, 256, 37, 1):
+            set_option("conv_in_wgs", wgs)
+            eng.plan(B, Tp)
+            sc[wgs] = eng.score(x, y, t).clone()
+            h[wgs] = eng.debug_tensor("h_in").clone()
+    finally:
+        set_option("conv_in_wgs", 256)
+    assert torch.isfinite(h[512].float()).all() and float(h[512].float().abs().max()) > 0
+    for wgs in (256, 37, 1):
+        assert torch.equal(h[wgs], h[512]), wgs
+        d = float((sc[wgs] - sc[512]).abs().max() / sc[512].abs().max())
+        assert d < lp.fwd_bound(prec), (wgs, d)      # two valid 16-bit evaluations differ by less than either may differ from the fp32 oracle
+
+
 def test_backbone_interface_returns_network_output(golden_dir, sd_np):
     from universal_speech_enhancement_amd.sgmse.backbones import BackboneRegistry
     g = dict(np.load(os.path.join(golden_dir, "forward_large.npz")))

@@ -494,7 +494,7 @@ struct Fwd {
         // Large maps: the producer writes per-workgroup partial totals instead of queueing 640 atomics per item on each total; every consumer
         // of such a map goes through gn_coef (same threshold), which sums them.  (allocated in the dry run as well: the arena is sized by it)
         long long* part = (stats && g_stats_part && (long)a.H * a.W > g_gn_inline)
-                              ? (long long*)arena->alloc((size_t)B * std::max(conv_v4_tiles(a.H, a.W), 256) * w.cout * 2 * sizeof(long long)) : nullptr;
+                              ? (long long*)arena->alloc((size_t)B * std::max(conv_v4_tiles(a.H, a.W), std::max(256, g_conv_in_wgs)) * w.cout * 2 * sizeof(long long)) : nullptr;
         if (h->dry) return o;
         ConvArgs p{};
         p.src0 = a.p; p.C0 = a.C; p.src1 = a2 ? a2->p : nullptr; p.C1 = a2 ? a2->C : 0; p.in_dtype = a.dtype;
@@ -934,6 +934,7 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_mfma16")) { wgrad_set_mfma16((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_blocks")) { wgrad_set_blocks((int)value); return USE_OK; }
+    if (!strcmp(name, "conv_in_wgs")) { if (value < 1 || value > 4096) return fail(USE_E_INVALID, "conv_in_wgs: 1 ... 4096"); g_conv_in_wgs = (int)value; return USE_OK; }
     if (!strcmp(name, "conv_sk_max_px")) { conv_sk_set_max_px((long)value); return USE_OK; }             // 0: conv_sk off
     return fail(USE_E_INVALID, "unknown option '%s'", name);
 }

@@ -33,7 +33,9 @@ constexpr int TILE_H = 8;    // conv output tile: 8 x 16 pixels = 128 GEMM rows
 constexpr int TILE_W = 16;
 
 inline int tiles_per_image(int H, int W) { return ((H + TILE_H - 1) / TILE_H) * ((W + TILE_W - 1) / TILE_W); }
-inline int conv_in_split_wgs(int H, int W) { const int nt = tiles_per_image(H, W), tpw = (nt + 255) / 256; return (nt + tpw - 1) / tpw; }   // conv_in_split_kernel: <= 256 workgroups per item
+extern int g_conv_in_wgs;                               // conv_in_split_kernel: most workgroups per item (use_set_option("conv_in_wgs"))
+inline int conv_in_split_tpw(int H, int W) { const int nt = tiles_per_image(H, W); return (nt + g_conv_in_wgs - 1) / g_conv_in_wgs; }
+inline int conv_in_split_wgs(int H, int W) { const int nt = tiles_per_image(H, W), tpw = conv_in_split_tpw(H, W); return (nt + tpw - 1) / tpw; }
 inline int conv_v2_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 15) / 16); }   // conv_v2_kernel: 16x16 tiles
 
 // Implicit-GEMM convolution (3x3 pad 1, or 1x1) with fused prologue / epilogue.

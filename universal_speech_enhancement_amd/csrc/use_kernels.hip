@@ -780,21 +780,34 @@ __global__ __launch_bounds__(256) void conv_in_split_kernel(ConvArgs p, int tile
         for (int c = 0; c < CH; ++c) { st_s[h2][c] = 0.f; st_q[h2][c] = 0.f; }
     TOUT* out = (TOUT*)p.out;
     const int t_end = min(ntiles, ((int)blockIdx.x + 1) * tiles_per_wg);
+    // Round 5: the halo of tile t + 1 (one 16-byte pixel per thread, 180 of 256 threads) is requested right after tile t's halo is in LDS and
+    // flies behind tile t's MFMAs and stores; every global access of the loop is an unconditional buffer access (outside the image: an
+    // out-of-range offset - loads return 0, stores are dropped), so the wait for the halo is a counted vmcnt that leaves the stores in flight.
+    static_assert(HALO <= 256, "one halo pixel per thread");
+    const int hy_t = tid / (TILE_W + 2), hx_t = tid - hy_t * (TILE_W + 2);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src) + (size_t)b * p.H * p.W * 4, 0,
+                                                                            (unsigned)((size_t)p.H * p.W * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * p.H * p.W * p.Cout, 0,
+                                                                            (unsigned)((size_t)p.H * p.W * p.Cout * 2), 0x00020000);
+    auto halo_ld = [&](int tile) -> float4 {
+        const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
+        const int gy = ty0 + hy_t - 1, gx = tx0 + hx_t - 1;
+        const bool inb = tid < HALO && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, inb ? (unsigned)(gy * p.W + gx) * 16u : 0xfffffff0u, 0, 0));
+    };
+    float4 hv = halo_ld(min((int)blockIdx.x * tiles_per_wg, ntiles - 1));
     for (int tile = blockIdx.x * tiles_per_wg; tile < t_end; ++tile) {
         const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
-        for (int i = tid; i < HALO; i += 256) {
-            const int hy = i / (TILE_W + 2), hx = i - hy * (TILE_W + 2);
-            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = *reinterpret_cast<const float4*>(src + ((size_t)(b * p.H + gy) * p.W + gx) * 4);
-            const float xs[4] = {v.x, v.y, v.z, v.w};
+        if (tid < HALO) {
+            const float xs[4] = {hv.x, hv.y, hv.z, hv.w};
             __bf16 hi[4], lo[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) { hi[c] = (__bf16)xs[c]; lo[c] = (__bf16)(xs[c] - (float)hi[c]); }
-            *reinterpret_cast<uint2*>(s_x + i * 8) = *reinterpret_cast<const uint2*>(hi);
-            *reinterpret_cast<uint2*>(s_x + CINS_XB + i * 8) = *reinterpret_cast<const uint2*>(lo);
+            *reinterpret_cast<uint2*>(s_x + tid * 8) = *reinterpret_cast<const uint2*>(hi);
+            *reinterpret_cast<uint2*>(s_x + CINS_XB + tid * 8) = *reinterpret_cast<const uint2*>(lo);
         }
         __syncthreads();
+        hv = halo_ld(min(tile + 1, ntiles - 1));             // (past the walk's end: a harmless re-load)
         f32x16 acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -832,15 +845,17 @@ __global__ __launch_bounds__(256) void conv_in_split_kernel(ConvArgs p, int tile
             for (int q = 0; q < 32 / PPQ; ++q) {
                 const int row = q * PPQ + lane / CPR;
                 const int gy = ty0 + wave * 2 + (row >> 4), gx = tx0 + (row & 15);
-                if (co0 < p.Cout && gy < p.H && gx < p.W) {
-                    float v[CH];
+                const bool ok = co0 < p.Cout && gy < p.H && gx < p.W;
+                float v[CH];
 #pragma unroll
-                    for (int c4 = 0; c4 < CH / 4; ++c4) {
-                        const float4 t4 = *reinterpret_cast<const float4*>(stg + row * CINS_SP + ch * CH + c4 * 4);
-                        v[c4 * 4] = t4.x; v[c4 * 4 + 1] = t4.y; v[c4 * 4 + 2] = t4.z; v[c4 * 4 + 3] = t4.w;
-                    }
-                    const uint4 packed = Vec16<TOUT>::pack(v);
-                    *reinterpret_cast<uint4*>(out + ((size_t)(b * p.H + gy) * p.W + gx) * p.Cout + co0) = packed;
+                for (int c4 = 0; c4 < CH / 4; ++c4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(stg + row * CINS_SP + ch * CH + c4 * 4);
+                    v[c4 * 4] = t4.x; v[c4 * 4 + 1] = t4.y; v[c4 * 4 + 2] = t4.z; v[c4 * 4 + 3] = t4.w;
+                }
+                const uint4 packed = Vec16<TOUT>::pack(v);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, packed), rs_o,
+                                                       ok ? (unsigned)((gy * p.W + gx) * p.Cout + co0) * 2u : 0xfffffff0u, 0, 0);
+                if (ok) {
                     float vr[CH];
                     Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&packed), vr);       // statistics of the stored values
 #pragma unroll
@@ -878,6 +893,7 @@ __global__ __launch_bounds__(256) void conv_in_split_kernel(ConvArgs p, int tile
         }
     }
 }
+int g_conv_in_wgs = 256;
 static bool conv_in_eligible(const ConvArgs& a) {
     return a.in_dtype == DT_F32 && a.C0 == 4 && a.C1 == 0 && a.ntaps == 9 && !a.coef && !a.act && !a.res && !a.pyr && !a.temb &&
            a.XC0 + a.XC1 == 0 && a.Cout % 8 == 0;
@@ -947,7 +963,7 @@ void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
     }
     if (conv_in_eligible(a)) {
         dim3 grid(tiles_per_image(a.H, a.W), (a.Cout + 127) / 128, a.B);
-        const int ntiles = tiles_per_image(a.H, a.W), tpw = (ntiles + 255) / 256;       // <= 256 workgroups per item
+        const int tpw = conv_in_split_tpw(a.H, a.W);
         dim3 grid_s(conv_in_split_wgs(a.H, a.W), (a.Cout + 127) / 128, a.B);
         if (a.out_dtype == DT_BF16)     { if (a.wb) hipLaunchKernelGGL((conv_in_split_kernel<__bf16>), grid_s, dim3(256), 0, s, a, tpw);
                                           else      hipLaunchKernelGGL((conv_in_kernel<__bf16>), grid, dim3(256), 0, s, a); }
