@@ -70,7 +70,7 @@ typedef struct use_sampler_config {
  * finalisation sums them, instead of 64-bit atomics on the item's totals - integer sums either way: bit-identical results (read at use_plan).
  * "fir_strip" (default 1): the res-block down-sampler walks 8- or 4-row strips (0: the 2 x 2 block form; 8 / 4: forced) - bit-identical.
  * "conv_in_wgs" (default 256): most workgroups per item of the input convolution (each walks tiles / conv_in_wgs tiles; stored values do not depend on it).
- * Others: "stagger_level", "gn_inline", "plan_cache", "attn_fused", "pyr_pipe", "conv_sk_max_px", "wgrad_mfma16", "wgrad_blocks" (INTEGRATION.md). */
+ * Others: "stagger_level", "gn_inline", "plan_cache", "attn_fused", "pyr_ws", "conv_sk_max_px", "wgrad_mfma16", "wgrad_blocks" (INTEGRATION.md). */
 int use_set_option(const char* name, long long value);
 const char* use_last_error(void);
 const char* use_version(void);

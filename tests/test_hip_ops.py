@@ -144,6 +144,55 @@ def test_fir_down_strip_walk_equals_the_block_form(dt, shape):
             assert torch.equal(outs[mode][k], outs[0][k]), (shape, dt, k, mode)
 
 
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 24, 48, 128, 1), (3, 16, 32, 256, 1), (1, 40, 16, 128, 0), (2, 13, 21, 128, 1)])
+def test_pyramid_head_forms_agree_bit_for_bit_and_match_torch(dt, shape):
+    """The output-pyramid head (GroupNorm affine + SiLU -> conv3x3 to 4 fp32 channels + the incoming pyramid; ncsnpp.py:437-470) in its two
+    schedules: pyr_conv_ws_kernel (round 5: producer / consumer waves walking several tiles per workgroup, the default; walks of many, few
+    and single tiles) and pyr_conv_kernel (one tile per workgroup).  Every output accumulates the same products in the same order => BIT-identical fp32 outputs; and all of them against a torch
+    fp32 convolution of the activated input rounded to the storage type (bound: accumulation order over K = 9 x C only, 2e-5 of the maximum).
+    Shapes: 128 and 256 channels (one / two blocks per tile), ragged map edges, no activation, walks of several tiles per workgroup."""
+    from universal_speech_enhancement_amd.hip_engine import set_option
+    B, H, W, Cc, act = shape
+    tdt = torch.bfloat16 if dt == 1 else torch.float16
+    g = torch.Generator().manual_seed(H * 1000 + W + Cc)
+    x = (torch.randn(B, H, W, Cc, generator=g) * 1.2).to(tdt)
+    coef = torch.stack([0.5 + torch.rand(B, Cc, generator=g), torch.randn(B, Cc, generator=g) * 0.3], dim=-1).contiguous()
+    w = torch.randn(4, Cc, 3, 3, generator=g) * (1.0 / (3.0 * Cc ** 0.5))
+    bias = torch.randn(4, generator=g) * 0.1
+    res = torch.randn(B, H, W, 4, generator=g)
+    xd, cd, rd = x.cuda(), coef.cuda(), res.cuda().contiguous()
+
+    def run():
+        out = torch.empty(B, H, W, 4, dtype=torch.float32, device="cuda")
+        op = UseConvOp()
+        op.B, op.H, op.W, op.Cout, op.ntaps, op.act, op.dtype, op.out_dtype, op.variant = B, H, W, 4, 9, act, dt, 0, 0
+        op.C0, op.src0, op.C1, op.XC0, op.XC1 = Cc, xd.data_ptr(), 0, 0, 0
+        wn = np.ascontiguousarray(w.numpy(), dtype=np.float32); bn = np.ascontiguousarray(bias.numpy(), dtype=np.float32)
+        op.w, op.bias, op.coef, op.res = wn.ctypes.data, bn.ctypes.data, cd.data_ptr(), rd.data_ptr()
+        op.out_scale, op.out = 1.0, out.data_ptr()
+        check(_lib.lib().use_op_conv(C.byref(op), _stream()), "use_op_conv")
+        torch.cuda.synchronize()
+        return out.cpu()
+    outs = {}
+    try:
+        for name, ws in (("ws", 1), ("ws_few", 7), ("ws_many", 1000), ("tile", 0)):
+            set_option("pyr_ws", ws)
+            outs[name] = run()
+    finally:
+        set_option("pyr_ws", 1)
+    for name in ("ws_few", "ws_many", "tile"):
+        assert torch.equal(outs[name], outs["ws"]), (shape, dt, name)
+    # torch fp32 reference on the operands as the kernel sees them: weights and the activated input rounded to the storage type
+    a = x.float() * coef[:, None, None, :, 0] + coef[:, None, None, :, 1]
+    if act:
+        a = torch.nn.functional.silu(a)
+    a = a.to(tdt).float().permute(0, 3, 1, 2)
+    want = torch.nn.functional.conv2d(a, w.to(tdt).float(), bias, padding=1).permute(0, 2, 3, 1) + res
+    err = float((outs["ws"] - want).abs().max() / want.abs().max())
+    assert err < (2e-3 if dt == 1 else 3e-4), err                    # the device SiLU uses v_exp / v_rcp: the activated value may round to a neighbour
+
+
 def _run_resblock(g, dt, variant, up=False, down=False, split=None):
     """One ResnetBlockBigGANpp through the HIP operators; split = channels of the first of two concatenated sources."""
     x, temb = torch.from_numpy(g["x"]), torch.from_numpy(g["temb"])

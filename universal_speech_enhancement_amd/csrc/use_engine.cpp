@@ -931,7 +931,7 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
     if (!strcmp(name, "fir_strip")) { fir_set_strip((int)value); return USE_OK; }
-    if (!strcmp(name, "pyr_pipe")) { pyr_conv_set_pipe((int)value); return USE_OK; }
+    if (!strcmp(name, "pyr_ws")) { pyr_conv_set_ws((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_mfma16")) { wgrad_set_mfma16((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_blocks")) { wgrad_set_blocks((int)value); return USE_OK; }
     if (!strcmp(name, "conv_in_wgs")) { if (value < 1 || value > 4096) return fail(USE_E_INVALID, "conv_in_wgs: 1 ... 4096"); g_conv_in_wgs = (int)value; return USE_OK; }

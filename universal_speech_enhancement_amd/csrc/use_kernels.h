@@ -92,7 +92,7 @@ bool conv_sk_eligible(const ConvArgs& a);
 void conv_sk_set_max_px(long n);                         // largest map (H*W) it is used for (default 16x20)
 void launch_conv_sk(const ConvArgs& a, hipStream_t s);
 void launch_conv_generic(const ConvArgs& a, hipStream_t s);   // conv_kernel / pyr_conv_kernel / conv_in_kernel only (no specialised schedule)
-void pyr_conv_set_pipe(int n);                          // pyramid-head convolution: workgroups per item of the pipelined form (0: off)
+void pyr_conv_set_ws(int n);                            // wave-specialised form of the same layer (0: off, 1: on, n > 1: workgroups per launch)
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 80 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);

@@ -28,6 +28,12 @@
 
 namespace use {
 
+// Workgroup barrier that orders LDS only (round 5).  __syncthreads() carries a release fence, i.e. s_waitcnt vmcnt(0): loads in flight for
+// the NEXT tile / unit and the acknowledgement of the stores just issued would be waited for at every barrier of a tile walk (pyr_conv_ws:
+// 3 us per unit whatever else the unit did).  For barriers that only separate LDS writes from LDS reads of the same workgroup.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+
 // ---------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution
 // ---------------------------------------------------------------------------------------------------------
@@ -427,12 +433,6 @@ __global__ __launch_bounds__(256) void pyr_conv_kernel(ConvArgs p) {
         }
     }
 }
-// pyr_conv_pipe_kernel: the same layer, software-pipelined.  PMC of pyr_conv_kernel at 512x640: waves parked 47 % of their cycles,
-// VALU active 18 %, MFMA 12 % -- a workgroup loads its halo, waits, transforms, synchronises, multiplies, stores, and the two
-// workgroups a CU holds do not cover each other's waits.  Here a workgroup walks `tiles_per_wg` consecutive tiles of one item and
-// issues the halo loads of tile t+1 (registers) BEFORE it transforms and multiplies tile t; the weights of all taps (<= 2 blocks of
-// 128 input channels) and the GroupNorm affine of its channels are fetched once per workgroup.  Same arithmetic, same order.
-constexpr int PYRP_SMEM = PYR_HALO + 2 * PYR_WB + BM * 4 * 4;
 // 16x16x32 MFMA for the head: the 32x32x16 form computes 32 output columns of which 4 exist and chains all 36 MFMAs of a (tile, block)
 // unit through ONE accumulator (the matrix pipe's dependent-issue latency, not its rate, set the unit's duration); the 16x16x32 form has
 // a quarter of the passes per instruction and gives each wave two independent accumulators (its two 16-pixel rows).
@@ -443,171 +443,187 @@ template <> struct Mfma16<__bf16> {
 template <> struct Mfma16<_Float16> {
     DEVI static f32x4 mma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
-// (round 4: ONEBLK / ACT as compile-time constants - with a run-time block index hipcc selected each of the 16 affine coefficients per
-// piece, 2 v_cndmask per staged element beside the 7.5 instructions of the transform itself)
 #ifndef USE_PYR_ABL
-#define USE_PYR_ABL 0                /* timing-only ablations: 1 no transform, 2 no MFMAs, 4 no residual / bias loads in the epilogue */
+#define USE_PYR_ABL 0                /* timing-only ablations of pyr_conv_ws_kernel: 1 no SiLU, 2 one MFMA pair per unit */
 #endif
+// pyr_conv_ws_kernel (round 5): the same layer with its two halves on different waves.  The round-4 form (pyr_conv_pipe_kernel: a 4-wave
+// workgroup walks tiles with the next halo's loads in flight, two workgroups per CU) had parts that ADD UP - loads + LDS + stores 81 us,
+// SiLU 67 us (the VALU rate of v_exp + v_rcp on a 1.4x halo), MFMAs + fragment reads 44 us of 191 us: a workgroup transforms,
+// synchronises, multiplies, and the two workgroups of a CU run in step.  Here ONE workgroup of eight waves per CU: waves 4-7 (one per
+// SIMD) load, normalise, activate and stage the halo of unit u + 1 into the second of two LDS halo buffers while waves 0-3 (one per
+// SIMD) run the MFMAs and the stores of unit u - VALU and matrix pipe of a SIMD busy at the same time, one LDS-only barrier per unit;
+// the launch is one round of <= 256 workgroups.  163 -> 111 us per 3-item launch at 512x640 (profiles/r5_pyr_conv_ws.txt).  Measured and
+// left out: three register sets (loads two units ahead) and fragments requested a tap row ahead (each activation fragment read once) -
+// neither the memory latency nor the consumers bound the unit: with SiLU and MFMAs ablated the walk still takes 92 us.
+// Same arithmetic, same order per output as pyr_conv_kernel: bit-identical results (test_pyramid_head_forms_agree_bit_for_bit_and_match_torch).
+constexpr int PYRW_SMEM = 2 * PYR_HALO + 2 * PYR_WB + 4 * 32 * 4 * 4;
 template <typename T16, bool ONEBLK, bool ACT>
-__global__ __launch_bounds__(256) void pyr_conv_pipe_kernel(ConvArgs p, int tiles_per_wg) {
+__global__ __launch_bounds__(512) void pyr_conv_ws_kernel(ConvArgs p, int tiles_per_wg) {
     typedef Mfma<T16> MF;
     extern __shared__ __attribute__((aligned(16))) char psm[];
-    char* const s_halo = psm;
-    char* const s_w = psm + PYR_HALO;                         // [nblk <= 2][9 taps x 4 rows][PYR_ROWB]
-    float* const s_out = reinterpret_cast<float*>(psm + PYR_HALO + 2 * PYR_WB);   // [128 pixels][4]
+    char* const s_w = psm + 2 * PYR_HALO;                                        // [nblk <= 2][9 taps x 4 rows][PYR_ROWB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z;
     const int tiles_x = (p.W + TILE_W - 1) / TILE_W, ntiles = tiles_x * ((p.H + TILE_H - 1) / TILE_H);
-    const int Cin = p.C0, nblk = ONEBLK ? 1 : Cin / PYR_CB;   // 1 or 2
-    const T16* src = (const T16*)p.src0;
-    const int part = tid % PYR_PP;
-    const int m = lane & 31;
-    // 16x16x32 fragments: lane -> (pixel column | output channel) lane & 15, 8-channel k group lane >> 4; row i of the wave: + i * PYR_HPITCH
-    const int a_base = (wave * 2) * PYR_HPITCH + (lane & 15) * PYR_ROWB + (lane >> 4) * 16;
-    const int b_base = (lane & 3) * PYR_ROWB + (lane >> 4) * 16;
-    (void)m;
-    constexpr int NP = ((TILE_H + 2) * (TILE_W + 2) * PYR_PP + 255) / 256;
-    // weights of every block, once
-    for (int i = tid; i < nblk * 9 * 4 * PYR_PP; i += 256) {
+    const int Cin = p.C0, nblk = ONEBLK ? 1 : Cin / PYR_CB;                      // 1 or 2
+    for (int i = tid; i < nblk * 9 * 4 * PYR_PP; i += 512) {                     // weights of every block, once
         const int blk = i / (9 * 4 * PYR_PP), r0 = i - blk * (9 * 4 * PYR_PP);
-        const int pc = r0 % PYR_PP, row = r0 / PYR_PP;         // row = tap * 4 + co
+        const int pc = r0 % PYR_PP, row = r0 / PYR_PP;                           // row = tap * 4 + co
         const int tap = row >> 2, co = row & 3;
         *reinterpret_cast<uint4*>(s_w + blk * PYR_WB + row * PYR_ROWB + pc * 16) =
             *reinterpret_cast<const uint4*>((const T16*)p.w + ((size_t)co * 9 + tap) * Cin + blk * PYR_CB + pc * 8);
     }
-    // GroupNorm affine of this thread's 8 channels of each block, once
-    float ca[2][8], cb[2][8];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            ca[blk][k] = 1.f; cb[blk][k] = 0.f;
-            if (blk < nblk) {
-                const int c = blk * PYR_CB + part * 8 + k;
-                if (p.gn_st0) {
-                    const float2 v = gn_coef_of(p.gn_st0, p.C0, p.gn_st1, p.C1, p.gn_gamma, p.gn_beta, p.gn_groups, p.gn_inv_n, p.gn_eps, b, c);
-                    ca[blk][k] = v.x; cb[blk][k] = v.y;
-                } else if (p.coef) {
-                    ca[blk][k] = p.coef[((size_t)b * Cin + c) * 2]; cb[blk][k] = p.coef[((size_t)b * Cin + c) * 2 + 1];
-                }
-            }
-        }
     const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
-    const int nunits = (t_end - t_begin) * nblk;
-    // Round 4: branch-free staging.  The thread's NP pieces are the same halo positions in every unit: their byte offset relative to the
-    // tile origin, their LDS destination and their (hy, hx) are computed once; a unit adds a scalar base and turns "outside the image"
-    // into an out-of-range buffer offset (the load returns 0, no divergent branch) and a zeroed result; pieces beyond the halo
-    // (the last, partial round) load nothing and store to spare bytes of the halo's first row.  Two register sets alternate, so the
-    // raw pieces are never copied.  Same arithmetic, same order as before.
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T16*>(src) + (size_t)b * p.H * p.W * Cin, 0,
-                                                                             (unsigned)((size_t)p.H * p.W * Cin * 2), 0x00020000);
-    int rel[NP], dbase[NP]; unsigned hyx[NP];
+    const int nunits = (t_end - t_begin) * nblk;                                 // unit = (tile, 128-channel block)
+    if (nunits <= 0) return;
+    const int nunits_pad = (nunits + 1) & ~1;                                     // barriers per walk, both sides (two register sets)
+    if (wave >= 4) {
+        // ---------------- producers: halo of unit u -> LDS buffer u & 1 (branch-free staging as in the pipelined form) ----------------
+        const int ptid = tid - 256;
+        const int part = ptid % PYR_PP;
+        const T16* src = (const T16*)p.src0;
+        constexpr int NP = ((TILE_H + 2) * (TILE_W + 2) * PYR_PP + 255) / 256;
+        float ca[2][8], cb[2][8];
 #pragma unroll
-    for (int jj = 0; jj < NP; ++jj) {
-        const int idx = jj * 256 + tid, pix = idx / PYR_PP;
-        const int hy = pix / (TILE_W + 2), hx = pix - hy * (TILE_W + 2);
-        const bool have = pix < (TILE_H + 2) * (TILE_W + 2);
-        rel[jj] = (((hy - 1) * p.W + (hx - 1)) * Cin + part * 8) * 2;
-        dbase[jj] = have ? hy * PYR_HPITCH + hx * PYR_ROWB + part * 16 : (TILE_W + 2) * PYR_ROWB + (tid & 7) * 16;
-        hyx[jj] = have ? (unsigned)(hy << 8 | hx) : 0xff00u;
-    }
-    static_assert((TILE_W + 2) * PYR_ROWB + 8 * 16 <= PYR_HPITCH, "spare bytes behind a halo row");
-    auto prefetch = [&](int u, uint4 (&raw)[NP], unsigned& ok) {   // unit u = (tile, block): issue its halo loads
-        u = min(u, nunits - 1);                                    // (past the end: the last unit again - unconditional loads keep hipcc's counted waits)
-        const int tile = t_begin + u / nblk, c0 = (u % nblk) * PYR_CB;
-        const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
-        const int base = ((ty0 * p.W + tx0) * Cin + c0) * 2;
-        ok = 0u;
-#pragma unroll
-        for (int jj = 0; jj < NP; ++jj) {
-            const int gy = ty0 + (int)(hyx[jj] >> 8) - 1, gx = tx0 + (int)(hyx[jj] & 255u) - 1;
-            const bool inb = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            ok |= inb ? 1u << jj : 0u;
-            raw[jj] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, inb ? (unsigned)(rel[jj] + base) : 0xfffffff0u, 0, 0));
-        }
-    };
-    f32x4 acc0, acc1;                                        // the wave's two 16-pixel rows
-    auto process = [&](int u, const uint4 (&raw)[NP], const unsigned ok) {
-        const int blk = ONEBLK ? 0 : u % nblk;
-        if (blk == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-        }
-        // the epilogue's residual (the incoming pyramid, fp32 [px][4]) is fetched now, behind the transform and the MFMAs (round 4:
-        // loaded where it was used it cost 31 of the kernel's 191 us)
-        const int tile_e = t_begin + u / nblk;
-        const int ty0e = (tile_e / tiles_x) * TILE_H, tx0e = (tile_e % tiles_x) * TILE_W;
-        const int gye = ty0e + (tid >> 4), gxe = tx0e + (tid & 15);
-        const bool out_ok = blk == nblk - 1 && tid < TILE_H * TILE_W && gye < p.H && gxe < p.W;
-        const size_t pixe = (size_t)(b * p.H + (out_ok ? gye : 0)) * p.W + (out_ok ? gxe : 0);
-        float rese[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.res && p.Cout == 4 && !(USE_PYR_ABL & 4)) {
-            const float4 r4 = *reinterpret_cast<const float4*>((const float*)p.res + pixe * 4);
-            rese[0] = r4.x; rese[1] = r4.y; rese[2] = r4.z; rese[3] = r4.w;
-        } else if (p.res && !(USE_PYR_ABL & 4)) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) if (c < p.Cout) rese[c] = ((const float*)p.res)[pixe * p.Cout + c];
-        }
-#pragma unroll
-        for (int jj = 0; jj < NP; ++jj) {
-            float v[8];
-            Vec16<T16>::load(reinterpret_cast<const T16*>(&raw[jj]), v);
+        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                v[k] = ONEBLK ? fmaf(v[k], ca[0][k], cb[0][k]) : fmaf(v[k], blk ? ca[1][k] : ca[0][k], blk ? cb[1][k] : cb[0][k]);
-                if (ACT && !(USE_PYR_ABL & 1)) v[k] = silu_f<false>(v[k]);
-            }
-            uint4 o = (USE_PYR_ABL & 1) ? raw[jj] : Vec16<T16>::pack(v);
-            const unsigned mk = ((ok >> jj) & 1u) ? 0xffffffffu : 0u;    // outside the image: the conv's zero padding
-            o.x &= mk; o.y &= mk; o.z &= mk; o.w &= mk;
-            *reinterpret_cast<uint4*>(s_halo + dbase[jj]) = o;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int tap = 0; tap < ((USE_PYR_ABL & 2) ? 1 : 9); ++tap) {
-            const char* ha = s_halo + a_base + (tap / 3) * PYR_HPITCH + (tap % 3) * PYR_ROWB;
-            const char* wb = s_w + blk * PYR_WB + b_base + tap * 4 * PYR_ROWB;
-#pragma unroll
-            for (int kk = 0; kk < ((USE_PYR_ABL & 2) ? 1 : PYR_CB / 32); ++kk) {
-                const auto wf = MF::ld(wb + kk * 64);
-                acc0 = Mfma16<T16>::mma(MF::ld(ha + kk * 64), wf, acc0);
-                acc1 = Mfma16<T16>::mma(MF::ld(ha + PYR_HPITCH + kk * 64), wf, acc1);
-            }
-        }
-        if (blk == nblk - 1) {                                // tile complete: [128 px][4] through LDS, one pixel per thread
-            if ((lane & 15) < 4) {                           // D of 16x16x32: column lane & 15 (output channel), rows 4 (lane >> 4) + r
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int col = 4 * (lane >> 4) + r;
-                    s_out[(wave * 32 + col) * 4 + (lane & 15)] = acc0[r];
-                    s_out[(wave * 32 + 16 + col) * 4 + (lane & 15)] = acc1[r];
+                ca[blk][k] = 1.f; cb[blk][k] = 0.f;
+                if (blk < nblk) {
+                    const int c = blk * PYR_CB + part * 8 + k;
+                    if (p.gn_st0) {
+                        const float2 v = gn_coef_of(p.gn_st0, p.C0, p.gn_st1, p.C1, p.gn_gamma, p.gn_beta, p.gn_groups, p.gn_inv_n, p.gn_eps, b, c);
+                        ca[blk][k] = v.x; cb[blk][k] = v.y;
+                    } else if (p.coef) {
+                        ca[blk][k] = p.coef[((size_t)b * Cin + c) * 2]; cb[blk][k] = p.coef[((size_t)b * Cin + c) * 2 + 1];
+                    }
                 }
             }
-            __syncthreads();                                  // also: every wave is done with the halo
-            if (out_ok) {
-                float4 v = *reinterpret_cast<const float4*>(s_out + tid * 4);
-                float o[4] = {v.x, v.y, v.z, v.w};
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T16*>(src) + (size_t)b * p.H * p.W * Cin, 0,
+                                                                                 (unsigned)((size_t)p.H * p.W * Cin * 2), 0x00020000);
+        int rel[NP], dbase[NP]; unsigned hyx[NP];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (c < p.Cout && p.bias && !(USE_PYR_ABL & 4)) o[c] += p.bias[c];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] += rese[c];
-                float* op = (float*)p.out + pixe * p.Cout;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) if (c < p.Cout) op[c] = o[c] * p.out_scale;
-            }
-        } else {
-            __syncthreads();                                  // every wave is done with the halo of this block
+        for (int jj = 0; jj < NP; ++jj) {
+            const int idx = jj * 256 + ptid, pix = idx / PYR_PP;
+            const int hy = pix / (TILE_W + 2), hx = pix - hy * (TILE_W + 2);
+            const bool have = pix < (TILE_H + 2) * (TILE_W + 2);
+            rel[jj] = (((hy - 1) * p.W + (hx - 1)) * Cin + part * 8) * 2;
+            dbase[jj] = have ? hy * PYR_HPITCH + hx * PYR_ROWB + part * 16 : (TILE_W + 2) * PYR_ROWB + (ptid & 7) * 16;   // (spare bytes behind a halo row)
+            hyx[jj] = have ? (unsigned)(hy << 8 | hx) : 0xff00u;
         }
-    };
-    if (nunits <= 0) return;
-    uint4 rawA[NP], rawB[NP]; unsigned okA = 0u, okB = 0u;
-    prefetch(0, rawA, okA);
-    for (int u = 0; u < nunits; u += 2) {
-        prefetch(u + 1, rawB, okB);                           // in flight behind this unit's transform + MFMAs
-        process(u, rawA, okA);
-        if (u + 1 < nunits) {
-            prefetch(u + 2, rawA, okA);
-            process(u + 1, rawB, okB);
+        auto prefetch = [&](int u, uint4 (&raw)[NP], unsigned& ok) {
+            u = min(u, nunits - 1);                                              // (past the end: the last unit again - unconditional loads keep the counted waits)
+            const int tile = t_begin + u / nblk, c0 = (u % nblk) * PYR_CB;
+            const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
+            const int base = ((ty0 * p.W + tx0) * Cin + c0) * 2;
+            ok = 0u;
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {
+                const int gy = ty0 + (int)(hyx[jj] >> 8) - 1, gx = tx0 + (int)(hyx[jj] & 255u) - 1;
+                const bool inb = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                ok |= inb ? 1u << jj : 0u;
+                raw[jj] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, inb ? (unsigned)(rel[jj] + base) : 0xfffffff0u, 0, 0));
+            }
+        };
+        auto stage = [&](int u, const uint4 (&raw)[NP], const unsigned ok) {
+            const int blk = ONEBLK ? 0 : u % nblk;
+            char* const hb = psm + (u & 1) * PYR_HALO;
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {
+                float v[8];
+                Vec16<T16>::load(reinterpret_cast<const T16*>(&raw[jj]), v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k] = ONEBLK ? fmaf(v[k], ca[0][k], cb[0][k]) : fmaf(v[k], blk ? ca[1][k] : ca[0][k], blk ? cb[1][k] : cb[0][k]);
+                    if (ACT && !(USE_PYR_ABL & 1)) v[k] = silu_f<false>(v[k]);
+                }
+                uint4 o = Vec16<T16>::pack(v);
+                const unsigned mk = ((ok >> jj) & 1u) ? 0xffffffffu : 0u;        // outside the image: the conv's zero padding
+                o.x &= mk; o.y &= mk; o.z &= mk; o.w &= mk;
+                *reinterpret_cast<uint4*>(hb + dbase[jj]) = o;
+            }
+        };
+        constexpr int NSETS = 2;                                                 // register sets: the loads of unit u + 1 fly behind the transform of unit u
+        uint4 raw[NSETS][NP]; unsigned ok[NSETS];
+#pragma unroll
+        for (int q = 0; q < NSETS - 1; ++q) prefetch(q, raw[q], ok[q]);
+        // (the walk is padded to a multiple of NSETS units - the padding units re-stage the last unit into a buffer nobody reads any more -
+        // so that the body has no conditional: with `if (u + q < nunits)` around a unit hipcc copies register sets between the branches and
+        // waits for all loads before it issues the next ones)
+        for (int u = 0; u < nunits_pad; u += NSETS) {
+#pragma unroll
+            for (int q = 0; q < NSETS; ++q) {
+                prefetch(u + q + NSETS - 1, raw[(q + NSETS - 1) % NSETS], ok[(q + NSETS - 1) % NSETS]);
+                __builtin_amdgcn_sched_barrier(0);                               // (the loads first: hipcc hoists the unpacking of the staged set above them, behind a vmcnt(0))
+                stage(u + q, raw[q], ok[q]);
+                LDS_BARRIER();                                                 // unit u + q staged; the consumers are done with the unit before it
+            }
+        }
+    } else {
+        // ---------------- consumers: 72 MFMAs per unit and wave, the tile's [128 px][4] leave through a per-wave LDS transposition ----------------
+        float* const s_out = reinterpret_cast<float*>(psm + 2 * PYR_HALO + 2 * PYR_WB) + wave * 128;    // [32 px][4]
+        // 16x16x32 fragments: lane -> (pixel column | output channel) lane & 15, 8-channel k group lane >> 4; row i of the wave: + i * PYR_HPITCH
+        const int a_base = (wave * 2) * PYR_HPITCH + (lane & 15) * PYR_ROWB + (lane >> 4) * 16;
+        const int b_base = (lane & 3) * PYR_ROWB + (lane >> 4) * 16;
+        f32x4 acc0, acc1;                                                        // the wave's two 16-pixel rows
+        for (int u = 0; u < nunits_pad; ++u) {
+            if (u >= nunits) { LDS_BARRIER(); continue; }                     // padding units of the producers' walk
+            const int blk = ONEBLK ? 0 : u % nblk;
+            if (blk == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            }
+            // this lane's output pixel (lanes 0-31: tile row 2 wave + (lane >> 4), column lane & 15); its residual is fetched ahead of the MFMAs
+            const int tile = t_begin + u / nblk;
+            const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
+            const int gy = ty0 + wave * 2 + ((lane >> 4) & 1), gx = tx0 + (lane & 15);
+            const bool out_ok = blk == nblk - 1 && lane < 32 && gy < p.H && gx < p.W;
+            const size_t pix = (size_t)(b * p.H + (out_ok ? gy : 0)) * p.W + (out_ok ? gx : 0);
+            float rese[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.res && p.Cout == 4) {
+                const float4 r4 = *reinterpret_cast<const float4*>((const float*)p.res + pix * 4);
+                rese[0] = r4.x; rese[1] = r4.y; rese[2] = r4.z; rese[3] = r4.w;
+            } else if (p.res) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < p.Cout) rese[c] = ((const float*)p.res)[pix * p.Cout + c];
+            }
+            LDS_BARRIER();                                                     // unit u is in buffer u & 1
+            const char* const hb = psm + (u & 1) * PYR_HALO + a_base;
+            const char* const wb = s_w + blk * PYR_WB + b_base;
+#pragma unroll
+            for (int tap = 0; tap < ((USE_PYR_ABL & 2) ? 1 : 9); ++tap) {
+                const char* ha = hb + (tap / 3) * PYR_HPITCH + (tap % 3) * PYR_ROWB;
+                const char* wt = wb + tap * 4 * PYR_ROWB;
+#pragma unroll
+                for (int kk = 0; kk < ((USE_PYR_ABL & 2) ? 1 : PYR_CB / 32); ++kk) {
+                    const auto wf = MF::ld(wt + kk * 64);
+                    acc0 = Mfma16<T16>::mma(MF::ld(ha + kk * 64), wf, acc0);
+                    acc1 = Mfma16<T16>::mma(MF::ld(ha + PYR_HPITCH + kk * 64), wf, acc1);
+                }
+            }
+            if (blk == nblk - 1) {
+                if ((lane & 15) < 4) {                                           // D of 16x16x32: column lane & 15 (output channel), rows 4 (lane >> 4) + r
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = 4 * (lane >> 4) + r;
+                        s_out[col * 4 + (lane & 15)] = acc0[r];
+                        s_out[(16 + col) * 4 + (lane & 15)] = acc1[r];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (out_ok) {
+                    float4 v = *reinterpret_cast<const float4*>(s_out + lane * 4);
+                    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (c < p.Cout && p.bias) o[c] += p.bias[c];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] += rese[c];
+                    float* op = (float*)p.out + pix * p.Cout;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (c < p.Cout) op[c] = o[c] * p.out_scale;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
 }
@@ -806,7 +822,7 @@ __global__ __launch_bounds__(256) void conv_in_split_kernel(ConvArgs p, int tile
             *reinterpret_cast<uint2*>(s_x + tid * 8) = *reinterpret_cast<const uint2*>(hi);
             *reinterpret_cast<uint2*>(s_x + CINS_XB + tid * 8) = *reinterpret_cast<const uint2*>(lo);
         }
-        __syncthreads();
+        LDS_BARRIER();                                          // LDS-only barrier: the previous tile's stores stay in flight
         hv = halo_ld(min(tile + 1, ntiles - 1));             // (past the walk's end: a harmless re-load)
         f32x16 acc[4];
 #pragma unroll
@@ -864,7 +880,7 @@ __global__ __launch_bounds__(256) void conv_in_split_kernel(ConvArgs p, int tile
             }
             __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();                                     // every wave is done with this tile's halo
+        LDS_BARRIER();                                          // every wave is done with this tile's halo (LDS-only: no wait for the stores' acknowledgement)
     }
     if (p.stats || p.stats_part) {
 #pragma unroll
@@ -928,8 +944,8 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     launch_conv_generic(a, s);
 }
 
-static int g_pyr_pipe = 128;      // workgroups per item of pyr_conv_pipe_kernel (0: the one-tile-per-workgroup form)
-void pyr_conv_set_pipe(int n) { g_pyr_pipe = n; }
+static int g_pyr_ws = 1;          // wave-specialised head: 0 the one-tile-per-workgroup form, 1 on (256 workgroups per launch), n > 1: n workgroups per launch
+void pyr_conv_set_ws(int n) { g_pyr_ws = n; }
 void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
     if (pyr_conv_eligible(a)) {
         static LdsAttrOnce attr_set;
@@ -938,23 +954,24 @@ void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, PYR_SMEM);
         }
         const int ntiles = tiles_per_image(a.H, a.W);
-        if (a.C0 <= 2 * PYR_CB && g_pyr_pipe) {              // pipelined form: <= 2 workgroups per CU worth of workgroups per item, several tiles each
-            static LdsAttrOnce attr2;
-            if (attr2.first()) {
-#define USE_PYRP_ATTR(T, O, A) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_pipe_kernel<T, O, A>), hipFuncAttributeMaxDynamicSharedMemorySize, PYRP_SMEM);
-                USE_PYRP_ATTR(__bf16, true, true) USE_PYRP_ATTR(__bf16, true, false) USE_PYRP_ATTR(__bf16, false, true) USE_PYRP_ATTR(__bf16, false, false)
-                USE_PYRP_ATTR(_Float16, true, true) USE_PYRP_ATTR(_Float16, true, false) USE_PYRP_ATTR(_Float16, false, true) USE_PYRP_ATTR(_Float16, false, false)
-#undef USE_PYRP_ATTR
+        if (a.C0 <= 2 * PYR_CB && g_pyr_ws) {                // wave-specialised form: one 8-wave workgroup per CU, the launch is one round of workgroups
+            static LdsAttrOnce attr3;
+            if (attr3.first()) {
+#define USE_PYRW_ATTR(T, O, A) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_ws_kernel<T, O, A>), hipFuncAttributeMaxDynamicSharedMemorySize, PYRW_SMEM);
+                USE_PYRW_ATTR(__bf16, true, true) USE_PYRW_ATTR(__bf16, true, false) USE_PYRW_ATTR(__bf16, false, true) USE_PYRW_ATTR(__bf16, false, false)
+                USE_PYRW_ATTR(_Float16, true, true) USE_PYRW_ATTR(_Float16, true, false) USE_PYRW_ATTR(_Float16, false, true) USE_PYRW_ATTR(_Float16, false, false)
+#undef USE_PYRW_ATTR
             }
-            const int tpw = (ntiles + g_pyr_pipe - 1) / g_pyr_pipe;
+            const int per_item = std::max(1, (g_pyr_ws > 1 ? g_pyr_ws : 256) / std::max(1, a.B));
+            const int tpw = (ntiles + per_item - 1) / per_item;
             const dim3 grid((ntiles + tpw - 1) / tpw, 1, a.B);
-            const bool one = a.C0 == PYR_CB, act = a.act != 0;
-#define USE_PYRP_GO(T) { if (one && act) hipLaunchKernelGGL((pyr_conv_pipe_kernel<T, true, true>), grid, dim3(256), PYRP_SMEM, s, a, tpw);      \
-                         else if (one) hipLaunchKernelGGL((pyr_conv_pipe_kernel<T, true, false>), grid, dim3(256), PYRP_SMEM, s, a, tpw);         \
-                         else if (act) hipLaunchKernelGGL((pyr_conv_pipe_kernel<T, false, true>), grid, dim3(256), PYRP_SMEM, s, a, tpw);         \
-                         else hipLaunchKernelGGL((pyr_conv_pipe_kernel<T, false, false>), grid, dim3(256), PYRP_SMEM, s, a, tpw); }
-            if (a.in_dtype == DT_BF16) USE_PYRP_GO(__bf16) else USE_PYRP_GO(_Float16)
-#undef USE_PYRP_GO
+            const bool one = a.C0 <= PYR_CB, act = a.act != 0;
+#define USE_PYRW_GO(T) { if (one && act) hipLaunchKernelGGL((pyr_conv_ws_kernel<T, true, true>), grid, dim3(512), PYRW_SMEM, s, a, tpw);      \
+                         else if (one) hipLaunchKernelGGL((pyr_conv_ws_kernel<T, true, false>), grid, dim3(512), PYRW_SMEM, s, a, tpw);         \
+                         else if (act) hipLaunchKernelGGL((pyr_conv_ws_kernel<T, false, true>), grid, dim3(512), PYRW_SMEM, s, a, tpw);         \
+                         else hipLaunchKernelGGL((pyr_conv_ws_kernel<T, false, false>), grid, dim3(512), PYRW_SMEM, s, a, tpw); }
+            if (a.in_dtype == DT_BF16) USE_PYRW_GO(__bf16) else USE_PYRW_GO(_Float16)
+#undef USE_PYRW_GO
             return;
         }
         if (a.in_dtype == DT_BF16) hipLaunchKernelGGL(pyr_conv_kernel<__bf16>, dim3(ntiles, 1, a.B), dim3(256), PYR_SMEM, s, a);
