@@ -334,7 +334,7 @@ def main():
         # what actually binds the kernel: the fused GroupNorm + SiLU costs two quarter-rate transcendentals per
         # staged element, which puts the FIR down-sampler (each input evaluated 2.25x) and the pyramid heads above their HBM time
         binds = {"fir_down": "valu (fused SiLU: v_exp + v_rcp per element, 1.7x redundant in the strip walk)",
-                 "pyr_conv": "tile walk (92 us with SiLU and MFMAs ablated) + valu (fused SiLU on a 1.4x halo), on producer waves beside the MFMA waves",
+                 "pyr_conv": "tile walk (65 us with SiLU and MFMAs ablated) + valu (fused SiLU, rolling halo 1.125x) on producer waves beside the MFMA waves",
                  "conv_in": "hbm write (tile walk, per-workgroup GroupNorm partial totals)", "fir_up": "hbm"}.get(name, "hbm")
         hbm_kernels.append({"kernel": name, "map": f"{Hm}x{Wm}", "launches_per_score": len(v), "algorithmic_bytes": round(by),
                             "avg_ms": round(ms, 4), "achieved_GBps": round(by / (ms * 1e-3) / 1e9, 1),

@@ -145,7 +145,7 @@ def test_fir_down_strip_walk_equals_the_block_form(dt, shape):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("shape", [(2, 24, 48, 128, 1), (3, 16, 32, 256, 1), (1, 40, 16, 128, 0), (2, 13, 21, 128, 1)])
+@pytest.mark.parametrize("shape", [(2, 24, 48, 128, 1), (3, 16, 32, 256, 1), (1, 40, 16, 128, 0), (2, 13, 21, 128, 1), (2, 64, 32, 128, 1)])
 def test_pyramid_head_forms_agree_bit_for_bit_and_match_torch(dt, shape):
     """The output-pyramid head (GroupNorm affine + SiLU -> conv3x3 to 4 fp32 channels + the incoming pyramid; ncsnpp.py:437-470) in its two
     schedules: pyr_conv_ws_kernel (round 5: producer / consumer waves walking several tiles per workgroup, the default; walks of many, few
@@ -176,12 +176,12 @@ def test_pyramid_head_forms_agree_bit_for_bit_and_match_torch(dt, shape):
         return out.cpu()
     outs = {}
     try:
-        for name, ws in (("ws", 1), ("ws_few", 7), ("ws_many", 1000), ("tile", 0)):
+        for name, ws in (("ws", 1), ("ws_few", 7), ("ws_one", 2), ("ws_many", 1000), ("tile", 0)):   # ws_one: one workgroup walks a whole item (rolling halo across strips)
             set_option("pyr_ws", ws)
             outs[name] = run()
     finally:
         set_option("pyr_ws", 1)
-    for name in ("ws_few", "ws_many", "tile"):
+    for name in ("ws_few", "ws_one", "ws_many", "tile"):
         assert torch.equal(outs[name], outs["ws"]), (shape, dt, name)
     # torch fp32 reference on the operands as the kernel sees them: weights and the activated input rounded to the storage type
     a = x.float() * coef[:, None, None, :, 0] + coef[:, None, None, :, 1]

@@ -31,6 +31,7 @@ namespace use {
 // Workgroup barrier that orders LDS only (round 5).  __syncthreads() carries a release fence, i.e. s_waitcnt vmcnt(0): loads in flight for
 // the NEXT tile / unit and the acknowledgement of the stores just issued would be waited for at every barrier of a tile walk (pyr_conv_ws:
 // 3 us per unit whatever else the unit did).  For barriers that only separate LDS writes from LDS reads of the same workgroup.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 
@@ -452,9 +453,12 @@ template <> struct Mfma16<_Float16> {
 // synchronises, multiplies, and the two workgroups of a CU run in step.  Here ONE workgroup of eight waves per CU: waves 4-7 (one per
 // SIMD) load, normalise, activate and stage the halo of unit u + 1 into the second of two LDS halo buffers while waves 0-3 (one per
 // SIMD) run the MFMAs and the stores of unit u - VALU and matrix pipe of a SIMD busy at the same time, one LDS-only barrier per unit;
-// the launch is one round of <= 256 workgroups.  163 -> 111 us per 3-item launch at 512x640 (profiles/r5_pyr_conv_ws.txt).  Measured and
-// left out: three register sets (loads two units ahead) and fragments requested a tap row ahead (each activation fragment read once) -
-// neither the memory latency nor the consumers bound the unit: with SiLU and MFMAs ablated the walk still takes 92 us.
+// the launch is one round of <= 256 workgroups.  With one 128-channel block per tile the walk runs DOWN a 16-pixel column strip and the
+// halo rolls (rows 0, 1 of a tile = rows 8, 9 of the tile above, copied LDS -> LDS: 1.125x instead of 1.41x redundant loads and SiLUs);
+// the consumers' residual is requested one tile ahead; every global access of the walk is an unconditional buffer access (counted
+// vmcnt waits that leave stores and prefetches in flight).  163 -> 91 us per 3-item launch at 512x640 (profiles/r5_pyr_conv_ws.txt).
+// Measured and left out: three register sets (loads two units ahead), fragments requested a tap row ahead with each activation
+// fragment read once (bursts of 24 ds_reads: 107 us), sched_group_barrier patterns (degenerate to read - wait - MFMA).
 // Same arithmetic, same order per output as pyr_conv_kernel: bit-identical results (test_pyramid_head_forms_agree_bit_for_bit_and_match_torch).
 constexpr int PYRW_SMEM = 2 * PYR_HALO + 2 * PYR_WB + 4 * 32 * 4 * 4;
 template <typename T16, bool ONEBLK, bool ACT>
@@ -476,13 +480,24 @@ __global__ __launch_bounds__(512) void pyr_conv_ws_kernel(ConvArgs p, int tiles_
     const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
     const int nunits = (t_end - t_begin) * nblk;                                 // unit = (tile, 128-channel block)
     if (nunits <= 0) return;
-    const int nunits_pad = (nunits + 1) & ~1;                                     // barriers per walk, both sides (two register sets)
+    constexpr int PYRW_SETS = 2;                                                 // register sets of the producers: the loads of unit u + 1 fly behind the transform of unit u
+    const int nunits_pad = (nunits + PYRW_SETS - 1) / PYRW_SETS * PYRW_SETS;      // barriers per walk, both sides
+    // walk order: down the 16-pixel column strips when the halo rolls (ONEBLK), row by row otherwise
+    const int tiles_y = (p.H + TILE_H - 1) / TILE_H;
+    auto tile_ty = [&](int tile) -> int { return ONEBLK ? tile % tiles_y : tile / tiles_x; };
+    auto tile_tx = [&](int tile) -> int { return ONEBLK ? tile / tiles_y : tile % tiles_x; };
     if (wave >= 4) {
         // ---------------- producers: halo of unit u -> LDS buffer u & 1 (branch-free staging as in the pipelined form) ----------------
         const int ptid = tid - 256;
         const int part = ptid % PYR_PP;
         const T16* src = (const T16*)p.src0;
-        constexpr int NP = ((TILE_H + 2) * (TILE_W + 2) * PYR_PP + 255) / 256;
+        // ROLL (one 128-channel block per tile): tiles are walked DOWN a 16-pixel column strip and the halo rolls - rows 0, 1 of a tile's halo are
+        // rows 8, 9 of the tile above, copied LDS -> LDS from the other buffer; only the 8 new rows are loaded, normalised and activated
+        // (1.41x -> 1.125x redundant loads and SiLUs).  The first tile of a walk / of a strip loads its two top rows itself.
+        constexpr bool ROLL = ONEBLK;
+        constexpr int HY0 = ROLL ? 2 : 0;                                        // first halo row of the prefetched body
+        constexpr int NPX = (TILE_H + 2 - HY0) * (TILE_W + 2);                   // body pixels: 144 (9 pieces per thread, none spare) / 180
+        constexpr int NP = (NPX * PYR_PP + 255) / 256;
         float ca[2][8], cb[2][8];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
@@ -505,8 +520,8 @@ __global__ __launch_bounds__(512) void pyr_conv_ws_kernel(ConvArgs p, int tiles_
 #pragma unroll
         for (int jj = 0; jj < NP; ++jj) {
             const int idx = jj * 256 + ptid, pix = idx / PYR_PP;
-            const int hy = pix / (TILE_W + 2), hx = pix - hy * (TILE_W + 2);
-            const bool have = pix < (TILE_H + 2) * (TILE_W + 2);
+            const int hy = HY0 + pix / (TILE_W + 2), hx = pix % (TILE_W + 2);
+            const bool have = pix < NPX;
             rel[jj] = (((hy - 1) * p.W + (hx - 1)) * Cin + part * 8) * 2;
             dbase[jj] = have ? hy * PYR_HPITCH + hx * PYR_ROWB + part * 16 : (TILE_W + 2) * PYR_ROWB + (ptid & 7) * 16;   // (spare bytes behind a halo row)
             hyx[jj] = have ? (unsigned)(hy << 8 | hx) : 0xff00u;
@@ -514,7 +529,7 @@ __global__ __launch_bounds__(512) void pyr_conv_ws_kernel(ConvArgs p, int tiles_
         auto prefetch = [&](int u, uint4 (&raw)[NP], unsigned& ok) {
             u = min(u, nunits - 1);                                              // (past the end: the last unit again - unconditional loads keep the counted waits)
             const int tile = t_begin + u / nblk, c0 = (u % nblk) * PYR_CB;
-            const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
+            const int ty0 = tile_ty(tile) * TILE_H, tx0 = tile_tx(tile) * TILE_W;
             const int base = ((ty0 * p.W + tx0) * Cin + c0) * 2;
             ok = 0u;
 #pragma unroll
@@ -525,25 +540,63 @@ __global__ __launch_bounds__(512) void pyr_conv_ws_kernel(ConvArgs p, int tiles_
                 raw[jj] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, inb ? (unsigned)(rel[jj] + base) : 0xfffffff0u, 0, 0));
             }
         };
+        // GroupNorm affine + SiLU of one 16-byte piece, two channels per instruction: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 are the same
+        // IEEE operations as the scalar forms of silu_f (the producers are bound by the VALU rate: 5.5 full-rate + 2 quarter-rate
+        // instructions per element before, 4 + 2 now); `mk` = 0 outside the image: the conv's zero padding
+        auto xform = [&](const uint4 rawp, const int blk, const unsigned mk) -> uint4 {
+            float v[8];
+            Vec16<T16>::load(reinterpret_cast<const T16*>(&rawp), v);
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                f32x2 t = {v[k], v[k + 1]};
+                const f32x2 a2 = {ONEBLK ? ca[0][k] : (blk ? ca[1][k] : ca[0][k]), ONEBLK ? ca[0][k + 1] : (blk ? ca[1][k + 1] : ca[0][k + 1])};
+                const f32x2 b2 = {ONEBLK ? cb[0][k] : (blk ? cb[1][k] : cb[0][k]), ONEBLK ? cb[0][k + 1] : (blk ? cb[1][k + 1] : cb[0][k + 1])};
+                t = __builtin_elementwise_fma(t, a2, b2);
+                if (ACT && !(USE_PYR_ABL & 1)) {
+                    f32x2 e = t * (f32x2){-1.44269504088896341f, -1.44269504088896341f};
+                    e.x = __builtin_amdgcn_exp2f(e.x); e.y = __builtin_amdgcn_exp2f(e.y);
+                    e = e + (f32x2){1.0f, 1.0f};
+                    e.x = __builtin_amdgcn_rcpf(e.x); e.y = __builtin_amdgcn_rcpf(e.y);
+                    t = t * e;
+                }
+                v[k] = t.x; v[k + 1] = t.y;
+            }
+            uint4 o = Vec16<T16>::pack(v);
+            o.x &= mk; o.y &= mk; o.z &= mk; o.w &= mk;
+            return o;
+        };
         auto stage = [&](int u, const uint4 (&raw)[NP], const unsigned ok) {
             const int blk = ONEBLK ? 0 : u % nblk;
             char* const hb = psm + (u & 1) * PYR_HALO;
+            if (ROLL) {                                                          // halo rows 0, 1: 36 px x 16 pieces, <= 3 per thread
+                const int uc = min(u, nunits - 1), tile = t_begin + uc;
+                const int ty = tile_ty(tile), tx = tile_tx(tile);
+                const bool cont = uc > 0 && ty != 0;                             // directly below the previous unit's tile (uniform)
+                const char* const hprev = psm + ((u & 1) ^ 1) * PYR_HALO;
 #pragma unroll
-            for (int jj = 0; jj < NP; ++jj) {
-                float v[8];
-                Vec16<T16>::load(reinterpret_cast<const T16*>(&raw[jj]), v);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    v[k] = ONEBLK ? fmaf(v[k], ca[0][k], cb[0][k]) : fmaf(v[k], blk ? ca[1][k] : ca[0][k], blk ? cb[1][k] : cb[0][k]);
-                    if (ACT && !(USE_PYR_ABL & 1)) v[k] = silu_f<false>(v[k]);
+                for (int k3 = 0; k3 < 3; ++k3) {
+                    const int idx = k3 * 256 + ptid, pix = idx / PYR_PP;         // pix < 36 for the pieces that exist
+                    const int hy = pix / (TILE_W + 2), hx = pix % (TILE_W + 2);
+                    const int d = hy * PYR_HPITCH + hx * PYR_ROWB + part * 16;
+                    if (pix < 2 * (TILE_W + 2)) {
+                        uint4 o;
+                        if (cont) o = *reinterpret_cast<const uint4*>(hprev + d + TILE_H * PYR_HPITCH);
+                        else {
+                            const int gy = ty * TILE_H + hy - 1, gx = tx * TILE_W + hx - 1;
+                            const bool inb = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                            const uint4 r = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                rs_in, inb ? (unsigned)(((gy * p.W + gx) * Cin + part * 8) * 2) : 0xfffffff0u, 0, 0));
+                            o = xform(r, 0, inb ? 0xffffffffu : 0u);
+                        }
+                        *reinterpret_cast<uint4*>(hb + d) = o;
+                    }
                 }
-                uint4 o = Vec16<T16>::pack(v);
-                const unsigned mk = ((ok >> jj) & 1u) ? 0xffffffffu : 0u;        // outside the image: the conv's zero padding
-                o.x &= mk; o.y &= mk; o.z &= mk; o.w &= mk;
-                *reinterpret_cast<uint4*>(hb + dbase[jj]) = o;
             }
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj)
+                *reinterpret_cast<uint4*>(hb + dbase[jj]) = xform(raw[jj], blk, ((ok >> jj) & 1u) ? 0xffffffffu : 0u);
         };
-        constexpr int NSETS = 2;                                                 // register sets: the loads of unit u + 1 fly behind the transform of unit u
+        constexpr int NSETS = PYRW_SETS;
         uint4 raw[NSETS][NP]; unsigned ok[NSETS];
 #pragma unroll
         for (int q = 0; q < NSETS - 1; ++q) prefetch(q, raw[q], ok[q]);
@@ -566,6 +619,29 @@ __global__ __launch_bounds__(512) void pyr_conv_ws_kernel(ConvArgs p, int tiles_
         const int a_base = (wave * 2) * PYR_HPITCH + (lane & 15) * PYR_ROWB + (lane >> 4) * 16;
         const int b_base = (lane & 3) * PYR_ROWB + (lane >> 4) * 16;
         f32x4 acc0, acc1;                                                        // the wave's two 16-pixel rows
+        // Output pixel of this lane in a tile (lanes 0-31: tile row 2 wave + (lane >> 4), column lane & 15).  Its residual (the incoming
+        // pyramid, fp32 [px][Cout]) is requested ONE TILE AHEAD and every global access of the walk is an unconditional dword buffer
+        // access (no pixel / no channel: an out-of-range offset), so the wait for it is a counted vmcnt that leaves the previous tile's
+        // stores in flight - fetched inside its own unit, its memory latency was the unit's duration (3 us with everything else ablated).
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((const float*)p.res) + (size_t)b * p.H * p.W * p.Cout, 0,
+                                                                                  p.res ? (unsigned)((size_t)p.H * p.W * p.Cout * 4) : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((float*)p.out + (size_t)b * p.H * p.W * p.Cout, 0,
+                                                                                (unsigned)((size_t)p.H * p.W * p.Cout * 4), 0x00020000);
+        auto px_off = [&](int tile) -> unsigned {                                // byte offset of channel 0 of this lane's pixel, or out of range
+            const int ty0 = tile_ty(tile) * TILE_H, tx0 = tile_tx(tile) * TILE_W;
+            const int gy = ty0 + wave * 2 + ((lane >> 4) & 1), gx = tx0 + (lane & 15);
+            return lane < 32 && gy < p.H && gx < p.W ? (unsigned)((gy * p.W + gx) * p.Cout) * 4u : 0xfffffff0u;
+        };
+        auto res_ld = [&](int tile, float (&r)[4]) {
+            const unsigned o = px_off(min(tile, t_end - 1));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, c < p.Cout ? o + 4u * c : 0xfffffff0u, 0, 0));
+        };
+        float bias4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bias4[c] = (c < p.Cout && p.bias) ? p.bias[c] : 0.f;
+        float rese[4], resn[4];
+        res_ld(t_begin, resn);
         for (int u = 0; u < nunits_pad; ++u) {
             if (u >= nunits) { LDS_BARRIER(); continue; }                     // padding units of the producers' walk
             const int blk = ONEBLK ? 0 : u % nblk;
@@ -573,19 +649,11 @@ __global__ __launch_bounds__(512) void pyr_conv_ws_kernel(ConvArgs p, int tiles_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
             }
-            // this lane's output pixel (lanes 0-31: tile row 2 wave + (lane >> 4), column lane & 15); its residual is fetched ahead of the MFMAs
             const int tile = t_begin + u / nblk;
-            const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
-            const int gy = ty0 + wave * 2 + ((lane >> 4) & 1), gx = tx0 + (lane & 15);
-            const bool out_ok = blk == nblk - 1 && lane < 32 && gy < p.H && gx < p.W;
-            const size_t pix = (size_t)(b * p.H + (out_ok ? gy : 0)) * p.W + (out_ok ? gx : 0);
-            float rese[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.res && p.Cout == 4) {
-                const float4 r4 = *reinterpret_cast<const float4*>((const float*)p.res + pix * 4);
-                rese[0] = r4.x; rese[1] = r4.y; rese[2] = r4.z; rese[3] = r4.w;
-            } else if (p.res) {
+            if (blk == nblk - 1) {                                               // the tile completes in this unit: its residual landed a unit ago
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (c < p.Cout) rese[c] = ((const float*)p.res)[pix * p.Cout + c];
+                for (int c = 0; c < 4; ++c) rese[c] = resn[c];
+                res_ld(tile + 1, resn);
             }
             LDS_BARRIER();                                                     // unit u is in buffer u & 1
             const char* const hb = psm + (u & 1) * PYR_HALO + a_base;
@@ -611,16 +679,14 @@ __global__ __launch_bounds__(512) void pyr_conv_ws_kernel(ConvArgs p, int tiles_
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (out_ok) {
-                    float4 v = *reinterpret_cast<const float4*>(s_out + lane * 4);
-                    float o[4] = {v.x, v.y, v.z, v.w};
+                {
+                    const float4 v = *reinterpret_cast<const float4*>(s_out + (lane & 31) * 4);
+                    const float o[4] = {v.x, v.y, v.z, v.w};
+                    const unsigned off = px_off(tile);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) if (c < p.Cout && p.bias) o[c] += p.bias[c];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] += rese[c];
-                    float* op = (float*)p.out + pix * p.Cout;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) if (c < p.Cout) op[c] = o[c] * p.out_scale;
+                    for (int c = 0; c < 4; ++c)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (o[c] + bias4[c] + rese[c]) * p.out_scale), rs_o,
+                                                              c < p.Cout ? off + 4u * c : 0xfffffff0u, 0, 0);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
