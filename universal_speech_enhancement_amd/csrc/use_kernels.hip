@@ -31,7 +31,6 @@ namespace use {
 // Workgroup barrier that orders LDS only (round 5).  __syncthreads() carries a release fence, i.e. s_waitcnt vmcnt(0): loads in flight for
 // the NEXT tile / unit and the acknowledgement of the stores just issued would be waited for at every barrier of a tile walk (pyr_conv_ws:
 // 3 us per unit whatever else the unit did).  For barriers that only separate LDS writes from LDS reads of the same workgroup.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 
@@ -1445,7 +1444,8 @@ __global__ __launch_bounds__(256) void fir_down_strip_kernel(const T* __restrict
                     float v[VEC], u[VEC];
                     Vec16<T>::load(src + ((size_t)(b * H + y) * W + min(max(x, 0), W - 1)) * C + c, v);
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) u[k] = silu_f<ACC>(fmaf(v[k], ca[k], cb[k]));
+                    for (int k = 0; k < VEC; ++k) u[k] = ACC ? silu_f<ACC>(fmaf(v[k], ca[k], cb[k])) : 0.f;
+                    if (!ACC) affine_silu_pk<VEC>(v, ca, cb, u);             // 16-bit storage: packed fp32, the same IEEE operations
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int t = e - 2 * j;
