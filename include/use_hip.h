@@ -69,7 +69,9 @@ typedef struct use_sampler_config {
  * above "gn_inline" pixels (default 128 x 160) the convolutions write per-workgroup GroupNorm partial totals with plain stores and the
  * finalisation sums them, instead of 64-bit atomics on the item's totals - integer sums either way: bit-identical results (read at use_plan).
  * "fir_strip" (default 1): the res-block down-sampler walks 8- or 4-row strips (0: the 2 x 2 block form; 8 / 4: forced) - bit-identical.
- * "conv_in_wgs" (default 256): most workgroups per item of the input convolution (each walks tiles / conv_in_wgs tiles; stored values do not depend on it).
+ * "conv_in_wgs" (default 256): most workgroups per item of the input convolution (each walks tiles / conv_in_wgs tiles; stored values do not depend on
+ * it; read at use_plan - options that size workspace buffers must not change between use_plan and the calls that use the plan: the library aborts with a
+ * message on a workspace overflow instead of corrupting memory).
  * Others: "stagger_level", "gn_inline", "plan_cache", "attn_fused", "pyr_ws", "conv_sk_max_px", "wgrad_mfma16", "wgrad_blocks" (INTEGRATION.md). */
 int use_set_option(const char* name, long long value);
 const char* use_last_error(void);

@@ -97,6 +97,10 @@ struct Arena {
         void* p = base ? (void*)(base + off) : nullptr;
         off += bytes;
         if (off > peak) peak = off;
+        if (base && off > cap) {     // cannot happen for the plan the arena was sized for: an option that sizes buffers (conv_in_wgs, stats_part, ...) changed after use_plan
+            fprintf(stderr, "libuse_hip: workspace arena overflow (%zu > %zu bytes): an option read at use_plan changed afterwards - call use_plan again\n", off, cap);
+            abort();
+        }
         return p;
     }
 };
