@@ -447,31 +447,10 @@ def gen_refine(model=None):
              weights_seed=4321, weights_crc=crc)
 
 
-def gen_lowprec(model=None):
-    """What the REFERENCE itself does in 16-bit arithmetic - the yardstick for the 16-bit tolerances of the HIP path (tests assert
-    "no worse than the reference's own reduced-precision run", never "2x what we measured last time").
-      forward: NCSNppLarge.forward on the forward_large inputs under torch.autocast("cpu", bfloat16 / float16) against its own fp32
-               output: error relative to the maximum and relative L2, per t-pair.
-      training: the reference's loss.backward() of gen_train_grads case a under bf16 autocast against its fp32 gradients: loss,
-               worst gradient-norm error, and per-tensor relative L2 errors (all 616 tensors: max, 99th / 95th percentile, median)."""
-    m, crc = model or build_reference_large()
-    g = dict(np.load(os.path.join(OUT, "forward_large.npz")))
-    x = torch.from_numpy(g["x"])
-    out = {}
-    for dt_name, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
-        for tag in ("a", "b"):
-            t = torch.from_numpy(g["t_" + tag])
-            ref = torch.from_numpy(g["out_" + tag])
-            try:
-                with torch.no_grad(), torch.autocast("cpu", dtype=dt):
-                    low = m.score_net(x, t)
-            except Exception as e:   # noqa: BLE001
-                print("  autocast", dt_name, "unsupported on this CPU build:", e)
-                continue
-            d = (torch.view_as_real(low.to(torch.complex64)) - torch.view_as_real(ref)).double()
-            out[f"fwd_{dt_name}_relmax_{tag}"] = np.float64(d.abs().max() / ref.abs().max())
-            out[f"fwd_{dt_name}_rell2_{tag}"] = np.float64(d.norm() / torch.view_as_real(ref).double().norm())
-            print(f"  forward {dt_name} {tag}: relmax {out[f'fwd_{dt_name}_relmax_{tag}']:.4g} rel-L2 {out[f'fwd_{dt_name}_rell2_{tag}']:.4g}", flush=True)
+def _lowprec_chain(m, out):
+    """The chain figures of lowprec_reference.npz (see gen_lowprec); round 6 adds the 99.99th percentile of |error| / max|reference| -
+    a statistic of the error's tail that, unlike the maximum over all elements, does not move by tens of per cent with the summation
+    order of a GroupNorm partial sum (tests/lowprec.py)."""
     # the benchmarked sampler as a chain: 30 PC steps (reverse_diffusion + Langevin x1 = 60 evaluations, t down to 0.03, the score's
     # 1/t amplification included) on one 0.4 s utterance, the reference under bf16 / fp16 autocast vs its own fp32 run, same noise:
     # how far the REFERENCE drifts in 16 bits (spectrogram fed to spec_back and waveform; relative to the maximum and relative L2)
@@ -502,8 +481,55 @@ def gen_lowprec(model=None):
             ref, low = chain["fp32"][i], chain[dt_name][i]
             out[f"chain_{dt_name}_{what}_relmax"] = np.float64((low - ref).abs().max() / ref.abs().max())
             out[f"chain_{dt_name}_{what}_rell2"] = np.float64((low - ref).norm() / ref.norm())
+            out[f"chain_{dt_name}_{what}_p9999"] = np.float64(np.quantile((low - ref).abs().numpy().ravel(), 0.9999) / float(ref.abs().max()))
         print("  chain", dt_name, {k: float(v) for k, v in out.items() if k.startswith(f"chain_{dt_name}")}, flush=True)
     out["chain_N"] = N_chain
+
+
+def gen_lowprec_chain(model=None):
+    """Re-run only the sampler-chain part of gen_lowprec and merge it into the existing lowprec_reference.npz: the figures that
+    were there must reproduce (same reference, same inputs, same thread count), the percentile keys are added."""
+    m, crc = model or build_reference_large()
+    path = os.path.join(OUT, "lowprec_reference.npz")
+    old = dict(np.load(path))
+    assert str(old["weights_crc"]) == str(crc)
+    out = {}
+    _lowprec_chain(m, out)
+    for k, v in out.items():
+        if k in old and not k.endswith("_p9999"):
+            assert abs(float(old[k]) - float(v)) <= 0.02 * abs(float(old[k])) + 1e-12, (k, float(old[k]), float(v))
+    kept = {k: v for k, v in old.items()}
+    kept.update({k: v for k, v in out.items() if k.endswith("_p9999")})      # the stored maxima / L2 figures stay as generated in round 4
+    np.savez(path, **kept)
+    print("  merged:", {k: float(v) for k, v in kept.items() if k.startswith("chain_")})
+
+
+def gen_lowprec(model=None):
+    """What the REFERENCE itself does in 16-bit arithmetic - the yardstick for the 16-bit tolerances of the HIP path (tests assert
+    "no worse than the reference's own reduced-precision run", never "2x what we measured last time").
+      forward: NCSNppLarge.forward on the forward_large inputs under torch.autocast("cpu", bfloat16 / float16) against its own fp32
+               output: error relative to the maximum and relative L2, per t-pair.
+      training: the reference's loss.backward() of gen_train_grads case a under bf16 autocast against its fp32 gradients: loss,
+               worst gradient-norm error, and per-tensor relative L2 errors (all 616 tensors: max, 99th / 95th percentile, median)."""
+    m, crc = model or build_reference_large()
+    g = dict(np.load(os.path.join(OUT, "forward_large.npz")))
+    x = torch.from_numpy(g["x"])
+    out = {}
+    for dt_name, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        for tag in ("a", "b"):
+            t = torch.from_numpy(g["t_" + tag])
+            ref = torch.from_numpy(g["out_" + tag])
+            try:
+                with torch.no_grad(), torch.autocast("cpu", dtype=dt):
+                    low = m.score_net(x, t)
+            except Exception as e:   # noqa: BLE001
+                print("  autocast", dt_name, "unsupported on this CPU build:", e)
+                continue
+            d = (torch.view_as_real(low.to(torch.complex64)) - torch.view_as_real(ref)).double()
+            out[f"fwd_{dt_name}_relmax_{tag}"] = np.float64(d.abs().max() / ref.abs().max())
+            out[f"fwd_{dt_name}_rell2_{tag}"] = np.float64(d.norm() / torch.view_as_real(ref).double().norm())
+            print(f"  forward {dt_name} {tag}: relmax {out[f'fwd_{dt_name}_relmax_{tag}']:.4g} rel-L2 {out[f'fwd_{dt_name}_rell2_{tag}']:.4g}", flush=True)
+    _lowprec_chain(m, out)
     # the refine generator (NCSNpp(discriminative=True), LSGAN stage) under bf16 autocast: the refine.npz input and the T' = 128 input of
     # tests/test_hip_parity.py::test_refine_generator_long_sequence_attention (1024-token attention)
     sdr = tw.make_state_dict(4321, **tw.REFINE)
@@ -579,8 +605,8 @@ if __name__ == "__main__":
              "refine": gen_refine, "forward_small": gen_forward_small, "both": gen_both,
              "train_loss": gen_train_loss, "train_grads": gen_train_grads}
     big = {"forward_large": gen_forward_large, "sample_e2e": gen_sample_e2e, "sample_cfg1": gen_sample_cfg1,
-           "sample_denoised": gen_sample_denoised, "lowprec": gen_lowprec}
-    todo = [a.only] if a.only else list(small) + list(big)
+           "sample_denoised": gen_sample_denoised, "lowprec": gen_lowprec, "lowprec_chain": gen_lowprec_chain}
+    todo = [a.only] if a.only else list(small) + [n for n in big if n != "lowprec_chain"]
     model = build_reference_large() if any(n in big for n in todo) else None
     for n in todo:
         print("generating", n, flush=True)

@@ -50,7 +50,7 @@ constexpr bool V4_XF_LEGACY = true;
 constexpr bool V4_XF_LEGACY = false;
 #endif
 
-template <typename TIN, typename TOUT, int CK, bool ACT>
+template <typename TIN, typename TOUT, int CK, bool ACT, int EPI>
 __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     typedef Mfma<TIN> MF;
     constexpr int VEC = 16 / sizeof(TIN);
@@ -89,6 +89,10 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     const int XCtot = p.XC0 + p.XC1, nchunks2 = XCtot / CK;
     const int part = tid & (PARTS - 1);
 
+    // (Round 6 measured a start-time spread of the first round's workgroups - all tiles of a launch take the same time, so the CUs of a lone
+    // launch run in lock step and every tile's 128 KB of output stores meet the memory system in the same few microseconds: with up to 32 k
+    // cycles of spread a launch repeated back to back is 3 % shorter, but in the three-stream evaluation, where other launches already
+    // scramble the phases, every cycle of delay is lost: +2 % at 32 k.  profiles/r6_conv_v4_epilogue_ab.txt.  Not kept.)
     float addv[TN];                                          // bias + time-embedding bias of this lane's channels
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -539,34 +543,48 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     const size_t img_elems = (size_t)p.H * p.W * p.Cout;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((TOUT*)p.out + (size_t)b * img_elems, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<TOUT*>((const TOUT*)p.res) + (size_t)b * img_elems, 0, 0x7fffffff, 0x00020000);
-    const unsigned voff = cok ? (unsigned)(((lane / CPR) * p.Cout + co0) * (int)sizeof(TOUT)) : 0u;
+    const unsigned voff = cok ? (unsigned)(((lane / CPR) * p.Cout + co0) * (int)sizeof(TOUT)) : 0x80000000u;   // beyond Cout: out of the descriptor's range
     const unsigned pass_b = (unsigned)(PPP * p.Cout) * (unsigned)sizeof(TOUT);      // bytes between passes
-    const bool has_res = p.res != nullptr, has_scale = p.out_scale != 1.f;
+    // Round 6: the epilogue is specialised at compile time (EPI >= 0: bit 0 residual, bit 1 out_scale, bit 2 Combine) and branch-free.
+    // With run-time flags every pass of a round was its own chain of basic blocks - ds_read, wait, (branch) add, (branch) multiply,
+    // (branch) Combine, (exec mask) pack + store - so each of the 16 passes of a wave paid the LDS latency and its own dependent chain
+    // with nothing of the next pass behind it (disassembly: four branches per pass).  Now a round reads ALL its pieces back first, the
+    // next round's staging stores and residual loads are issued behind those reads (DS operations of one wave execute in order), and the
+    // passes are straight-line code; lanes whose channels lie beyond Cout carry an out-of-range buffer offset (stores dropped, loads 0)
+    // instead of an exec mask.  EPI < 0 keeps the run-time flags (fp32 parity kernels: compile time).
+    constexpr bool EPI_RT = EPI < 0;
+    const bool has_res = EPI_RT ? p.res != nullptr : (EPI & 1) != 0;
+    const bool has_scale = EPI_RT ? p.out_scale != 1.f : (EPI & 2) != 0;
+    const bool has_pyr = EPI_RT ? p.pyr != nullptr : (EPI & 4) != 0;
+    constexpr bool PIPE = EPI >= 0 && !(EPI & 4) && sizeof(TOUT) == 2;   // round 1 staged behind round 0's reads (registers: not with the Combine set)
     constexpr bool HOIST_W4 = sizeof(TOUT) == 2;             // fp32 parity kernels: no registers to spare, in-loop loads
     // Combine ('sum') weights of this lane's channels: loop-invariant, fetched once (they were re-read per pixel piece)
     float4 w4r[CH]; float b4r[CH];
-    if (HOIST_W4 && p.pyr && cok) {
+    if (HOIST_W4 && has_pyr && cok) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) { w4r[c] = *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4); b4r[c] = p.b4[co0 + c]; }
     } else {
 #pragma unroll
         for (int c = 0; c < CH; ++c) { w4r[c] = make_float4(0.f, 0.f, 0.f, 0.f); b4r[c] = 0.f; }
     }
-    float st_s[CH], st_q[CH];
+    f32x2 st_s2[CH / 2], st_q2[CH / 2];                      // running (sum, sum of squares) of this lane's channels, as pairs
 #pragma unroll
-    for (int c = 0; c < CH; ++c) { st_s[c] = 0.f; st_q[c] = 0.f; }
+    for (int k = 0; k < CH / 2; ++k) { st_s2[k] = (f32x2){0.f, 0.f}; st_q2[k] = (f32x2){0.f, 0.f}; }
+    // (staging by ds_write_addtid_b32 - lane-linear rows, no address register, half the LDS-store cycles - was tried here in round 6: its
+    // base is M0[15:0], the eight waves' 16.5 KB regions reach past 64 KB, and the lone-launch stamps showed the rounds are not what
+    // bounds the epilogue anyway: the drain of the tile's 128 KB of output stores is)
+    const float* const stg_rd = stg + (lane / CPR) * STG_LD + ch * CH;       // pass q, 16-byte half c4: + q * PPP * STG_LD + 4 c4
+    auto stg_rd_off = [&](int q, int c4) -> int { return q * PPP * STG_LD + c4 * 4; };
+    auto row_bytes = [&](int i) -> unsigned {                // byte offset of this wave's tile row i inside the image (uniform)
+        return (unsigned)(((ty0 + wave_u * 2 + i) * p.W + tx0) * p.Cout) * (unsigned)sizeof(TOUT);
+    };
+    auto res_load = [&](int i, uint4 (&rv)[QN]) {
+        const unsigned row_b = row_bytes(i);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int gy = ty0 + wave_u * 2 + i;                 // this round's tile row (uniform)
-        const unsigned row_b = (unsigned)((gy * p.W + tx0) * p.Cout) * (unsigned)sizeof(TOUT);
-        // residual pieces of this round are fetched before the transposition (their latency overlaps it)
-        uint4 resv[QN];
-        if (has_res) {
-#pragma unroll
-            for (int q = 0; q < QN; ++q)
-                resv[q] = (V4_ABL & 8192) ? make_uint4(q, q, q, q) : __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff + row_b + (unsigned)q * pass_b, 0, V4_AUX_RES));
-        }
-        if (!(V4_ABL & 2048)) {
+        for (int q = 0; q < QN; ++q)
+            rv[q] = (V4_ABL & 8192) ? make_uint4(q, q, q, q) : __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff + row_b + (unsigned)q * pass_b, 0, V4_AUX_RES));
+    };
+    auto stage_write = [&](int i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -574,54 +592,114 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 stg[row * STG_LD + j * 32 + (lane & 31)] = acc[i][j][r];
             }
-        __builtin_amdgcn_wave_barrier();
+    };
+    // passes read back / finished together: all of a round (specialised forms), a quarter of a round with the Combine set (its weights take 40
+    // registers), one at a time with run-time flags (fp32 parity kernels: 16 passes of a round would not fit the register file)
+    constexpr int NQ = EPI_RT ? 1 : (EPI & 4) ? QN / 4 : QN;
+    auto stage_read = [&](int q0, f32x4 (&t)[NQ][CH / 4]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int c4 = 0; c4 < CH / 4; ++c4) t[q][c4] = *reinterpret_cast<const f32x4*>(stg_rd + stg_rd_off(q0 + q, c4));
+    };
+    auto finish = [&](int i, int q0, const f32x4 (&t)[NQ][CH / 4], const uint4 (&rv)[QN]) {
+        const int gy = ty0 + wave_u * 2 + i;                 // this round's tile row (uniform)
+        const unsigned row_b = row_bytes(i);
+        float4 pq[NQ];
+        if (has_pyr) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const size_t pix = (size_t)(b * p.H + gy) * p.W + tx0 + ((q0 + q) * 64 + lane) / CPR;
+                pq[q] = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
+            }
         }
 #pragma unroll
-        for (int q = 0; q < QN; ++q) {
-            const int row = (q * 64 + lane) / CPR;           // pixel column inside the tile row
-            float v[CH];
+        for (int q = 0; q < NQ; ++q) {
+            // arithmetic on channel PAIRS, spelled as 2-vectors: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 are the IEEE operations of the
+            // scalar forms at half the instruction count (left to the SLP vectoriser the statistics came out scalar once the pieces
+            // went through the asm pin above)
+            f32x2 v2[CH / 2];
 #pragma unroll
-            for (int c4 = 0; c4 < CH / 4; ++c4) {
-                const float4 t4 = (V4_ABL & 2048) ? make_float4(acc[i][c4 & 3][q & 15], acc[i][(c4 + 1) & 3][(q + 1) & 15], acc[i][(c4 + 2) & 3][(q + 2) & 15], acc[i][(c4 + 3) & 3][(q + 3) & 15])
-                                                  : *reinterpret_cast<const float4*>(stg + row * STG_LD + ch * CH + c4 * 4);
-                v[c4 * 4] = t4.x; v[c4 * 4 + 1] = t4.y; v[c4 * 4 + 2] = t4.z; v[c4 * 4 + 3] = t4.w;
-            }
+            for (int c4 = 0; c4 < CH / 4; ++c4) { v2[c4 * 2] = (f32x2){t[q][c4].x, t[q][c4].y}; v2[c4 * 2 + 1] = (f32x2){t[q][c4].z, t[q][c4].w}; }
             if (has_res) {
-                float rv[CH];
-                Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&resv[q]), rv);
+                float rvf[CH];
+                Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&rv[q0 + q]), rvf);
 #pragma unroll
-                for (int c = 0; c < CH; ++c) v[c] += rv[c];
+                for (int k = 0; k < CH / 2; ++k) v2[k] += (f32x2){rvf[2 * k], rvf[2 * k + 1]};
             }
             if (has_scale) {
 #pragma unroll
-                for (int c = 0; c < CH; ++c) v[c] *= p.out_scale;
+                for (int k = 0; k < CH / 2; ++k) v2[k] *= (f32x2){p.out_scale, p.out_scale};
             }
-            if (p.pyr) {
-                const size_t pix = (size_t)(b * p.H + gy) * p.W + tx0 + row;
-                const float4 pq = *reinterpret_cast<const float4*>(p.pyr + pix * 4);
+            float v[CH];
+#pragma unroll
+            for (int k = 0; k < CH / 2; ++k) { v[2 * k] = v2[k].x; v[2 * k + 1] = v2[k].y; }
+            if (has_pyr) {
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
                     const float4 wq = HOIST_W4 ? w4r[c] : (cok ? *reinterpret_cast<const float4*>(p.w4 + (size_t)(co0 + c) * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
-                    v[c] += (HOIST_W4 ? b4r[c] : (cok ? p.b4[co0 + c] : 0.f)) + wq.x * pq.x + wq.y * pq.y + wq.z * pq.z + wq.w * pq.w;
+                    v[c] += (HOIST_W4 ? b4r[c] : (cok ? p.b4[co0 + c] : 0.f)) + wq.x * pq[q].x + wq.y * pq[q].y + wq.z * pq[q].z + wq.w * pq[q].w;
                 }
             }
-            if (cok) {
-                const uint4 packed = Vec16<TOUT>::pack(v);
-                // (voffset carries the whole offset: with the uniform part in soffset, hipcc 7.2 mis-assigns the SGPR of one pass in
-                // the 16-pass fp32 instantiation - one VALU add per pass is the price of not depending on that)
-                if (V4_ABL & 1024) asm volatile("" :: "v"(packed.x), "v"(packed.y), "v"(packed.z), "v"(packed.w));
-                else
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, packed), rs_out,
-                                                       voff + row_b + (unsigned)q * pass_b, 0, V4_AUX_OUT);
-                if (!(V4_ABL & 4096)) {
+            if (!EPI_RT || cok) {                            // (specialised forms: no exec mask - lanes beyond Cout store out of range)
+            const uint4 packed = Vec16<TOUT>::pack(v);
+            if (V4_ABL & 1024) asm volatile("" :: "v"(packed.x), "v"(packed.y), "v"(packed.z), "v"(packed.w));
+            else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, packed), rs_out,
+                                                   voff + row_b + (unsigned)(q0 + q) * pass_b, 0, V4_AUX_OUT);
+            if (!(V4_ABL & 4096)) {
 #pragma unroll
-                for (int c = 0; c < CH; ++c) { st_s[c] += v[c]; st_q[c] = fmaf(v[c], v[c], st_q[c]); }
+                for (int k = 0; k < CH / 2; ++k) {
+                    const f32x2 x = {v[2 * k], v[2 * k + 1]};
+                    st_s2[k] += x; st_q2[k] = __builtin_elementwise_fma(x, x, st_q2[k]);
                 }
+            }
             }
         }
+    };
+    {
+        uint4 rv0[QN], rv1[QN];
+        f32x4 t[NQ][CH / 4];
+        if (has_res) res_load(0, rv0);
+        stage_write(0);
         __builtin_amdgcn_wave_barrier();
+        if constexpr (PIPE) {
+            // Left alone, LLVM puts every read back in front of its pass and pulls the passes' arithmetic up between the reads (pure
+            // arithmetic is ordered by nothing - not by sched_barrier, not by a memory clobber).  The pieces therefore pass through an
+            // empty volatile asm as in/out operands: everything computed from them follows it, all reads precede it.
+            auto pin = [&]() {
+                static_assert(NQ * (CH / 4) == 16, "16 pieces per round");
+                asm volatile("" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[3][0]), "+v"(t[3][1]),
+                                  "+v"(t[4][0]), "+v"(t[4][1]), "+v"(t[5][0]), "+v"(t[5][1]), "+v"(t[6][0]), "+v"(t[6][1]), "+v"(t[7][0]), "+v"(t[7][1]) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            stage_read(0, t);
+            if (has_res) res_load(1, rv1);
+            pin();
+            stage_write(1);                                  // behind the reads above in this wave's DS queue
+            asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+            finish(0, 0, t, rv0);
+            V4_STAMP(7)
+            asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+            stage_read(0, t);
+            pin();
+            finish(1, 0, t, rv1);
+        } else {
+#pragma unroll
+            for (int q0 = 0; q0 < QN; q0 += NQ) { stage_read(q0, t); finish(0, q0, t, rv0); }
+            V4_STAMP(7)
+            if (has_res) res_load(1, rv0);
+            __builtin_amdgcn_wave_barrier();
+            stage_write(1);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q0 = 0; q0 < QN; q0 += NQ) { stage_read(q0, t); finish(1, q0, t, rv0); }
+        }
         V4_STAMP(7)
     }
+    float st_s[CH], st_q[CH];
+#pragma unroll
+    for (int k = 0; k < CH / 2; ++k) { st_s[2 * k] = st_s2[k].x; st_s[2 * k + 1] = st_s2[k].y; st_q[2 * k] = st_q2[k].x; st_q[2 * k + 1] = st_q2[k].y; }
     if ((V4_ABL & 65536)) { float t = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) t += st_s[c] + st_q[c];
@@ -664,21 +742,34 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
 #endif
 }
 
-template <typename TIN, typename TOUT, int CK, bool ACT>
-static void v4_launch_t(const ConvArgs& a, hipStream_t s) {
+template <typename TIN, typename TOUT, int CK, bool ACT, int EPI>
+static void v4_launch_e(const ConvArgs& a, hipStream_t s) {
     constexpr int MAIN = 2 * V4_HH * 48 * 64 + 2 * V4_BN * 64 + 512 * 8 + 2 * 5 * 512 * 4;   // halo + weight buffers, GroupNorm table, piece tables
-    constexpr int EPI = 8 * 32 * (V4_BN + 4) * 4 + 8 * V4_BN * 2 * 4;
+    constexpr int EPIB = 8 * 32 * (V4_BN + 4) * 4 + 8 * V4_BN * 2 * 4;
 #ifdef USE_HIP_TRACE_BUILD
     constexpr int SMEM = 152064 + 2 * 248 * 8;               // + the stamp buffers
 #else
-    constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
+    constexpr int SMEM = MAIN > EPIB ? MAIN : EPIB;
 #endif
-    static_assert(MAIN <= 152064 && EPI <= 152064 && SMEM <= 163840, "LDS budget");
+    static_assert(MAIN <= 152064 && EPIB <= 152064 && SMEM <= 163840, "LDS budget");
     static LdsAttrOnce attr;                                 // per (instantiation, device)
-    auto kern = conv_v4_kernel<TIN, TOUT, CK, ACT>;
+    auto kern = conv_v4_kernel<TIN, TOUT, CK, ACT, EPI>;
     attr(kern, SMEM);
     dim3 grid(conv_v4_tiles(a.H, a.W), (a.Cout + V4_BN - 1) / V4_BN, a.B);
     hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, s, a);
+}
+
+// epilogue specialisation (conv_v4_kernel's EPI): the five flag sets the network produces; a set that is not instantiated runs on the
+// next larger one (a multiply by out_scale = 1 is exact).  fp32 storage (parity mode) keeps the run-time flags.
+template <typename TIN, typename TOUT, int CK, bool ACT>
+static void v4_launch_t(const ConvArgs& a, hipStream_t s) {
+    if constexpr (sizeof(TIN) == 4) { v4_launch_e<TIN, TOUT, CK, ACT, -1>(a, s); return; } else {
+    const bool res = a.res != nullptr, scale = a.out_scale != 1.f, pyr = a.pyr != nullptr;
+    if (pyr) { res ? v4_launch_e<TIN, TOUT, CK, ACT, 7>(a, s) : v4_launch_e<TIN, TOUT, CK, ACT, 6>(a, s); }
+    else if (res) v4_launch_e<TIN, TOUT, CK, ACT, 3>(a, s);
+    else if (scale) v4_launch_e<TIN, TOUT, CK, ACT, 2>(a, s);
+    else v4_launch_e<TIN, TOUT, CK, ACT, 0>(a, s);
+    }
 }
 
 static long g_v4_min_blocks = 80;      // (round 4: 128 -> 80: the 128 x 160 maps of the benchmark shape run 1.4 % of an evaluation faster here than on conv_v2)
