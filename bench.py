@@ -228,7 +228,8 @@ def main():
     def power_thread():
         try:
             from universal_speech_enhancement_amd.testing import smi
-            amdsmi, hnd = smi.smi_open()
+            amdsmi, hnd = smi.smi_open(pci_bus_id(local))      # the device this rank runs on, by PCI address (not amdsmi index 0)
+            probe["cap_W"] = smi.power_cap_watts(amdsmi, hnd)
             while not stop_probe.is_set():
                 probe["recs"].append(smi.sample(amdsmi, hnd))
                 stop_probe.wait(0.25)
@@ -237,7 +238,10 @@ def main():
         except Exception:                                       # no amdsmi on this box: rocm-smi's text output (power and clock only)
             probe["recs"] = []
         import re
+        import shutil
         import subprocess
+        if shutil.which("rocm-smi") is None:
+            return
         while not stop_probe.is_set():
             try:
                 o = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
@@ -280,7 +284,7 @@ def main():
             flat = {k: (max(v) if isinstance(v, list) and v else v) for k, v in lr.items()}     # per-XCD arrays -> their maximum
             power_probe = {"socket_W": sm["socket_W"], "sclk_MHz": sm.get("current_gfxclk"), "hotspot_C": sm.get("temperature_hotspot"),
                            "hbm_C": sm.get("temperature_mem"), "samples": sm["samples"], "window_s": sm.get("window_s"), "limit_reasons": flat,
-                           "power_cap_W": 1400,
+                           "power_cap_W": probe.get("cap_W"),
                            "source": "amdsmi in-process every 0.25 s during the timed steps (samples within 10 % of the maximum power); limit_reasons = "
                                      "share of that window in which the limiter was active (delta of its amdsmi violation accumulator / delta of acc_counter): "
                                      "ppt_pwr = socket power limit, *_thrm = thermal limiters"}

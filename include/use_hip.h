@@ -70,8 +70,12 @@ typedef struct use_sampler_config {
  * finalisation sums them, instead of 64-bit atomics on the item's totals - integer sums either way: bit-identical results (read at use_plan).
  * "fir_strip" (default 1): the res-block down-sampler walks 8- or 4-row strips (0: the 2 x 2 block form; 8 / 4: forced) - bit-identical.
  * "conv_in_wgs" (default 256): most workgroups per item of the input convolution (each walks tiles / conv_in_wgs tiles; stored values do not depend on
- * it; read at use_plan - options that size workspace buffers must not change between use_plan and the calls that use the plan: the library aborts with a
- * message on a workspace overflow instead of corrupting memory).
+ * it; read at use_plan).
+ * ALL options are read at use_plan (they size workspace buffers - "conv_in_wgs", "stats_part", "gn_inline", "subbatch*" - or choose kernels):
+ * every use_set_option marks the plans built before it stale.  use_score / use_forward / use_sample* / use_set_sampler on a stale plan return
+ * USE_E_STATE ("... call use_plan (and use_set_sampler) again" in use_last_error()); nothing is launched, the handle stays usable.  Should an
+ * evaluation still not fit its workspace the entry point returns USE_E_STATE as well (output invalid) - never a write past the allocation,
+ * never abort() (round 6; SURVEY 8b "never throw across the ABI").
  * Others: "stagger_level", "gn_inline", "plan_cache", "attn_fused", "pyr_ws", "conv_sk_max_px", "wgrad_mfma16", "wgrad_blocks" (INTEGRATION.md). */
 int use_set_option(const char* name, long long value);
 const char* use_last_error(void);

@@ -1,0 +1,89 @@
+// Sustained matrix-pipe rate and power of v_mfma_f32_32x32x16_bf16 vs v_mfma_f32_32x32x16_f16 on random data (round 6, VERDICT r5 #5: the
+// fp16 storage mode runs the same launches 4 % slower than bf16 - is it the matrix instruction itself under the power cap?).
+//   hipcc --offload-arch=gfx950 -O3 -o scripts/microbench/mfma_dtype_power scripts/microbench/mfma_dtype_power.hip
+//   python scripts/smi_probe.py --period 0.5 -- scripts/microbench/mfma_dtype_power <0 bf16 | 1 f16> <seconds> [waves per SIMD: 1 | 2]
+// One workgroup per CU (256 or 512 threads), every wave runs 16 independent accumulator tiles (2 x 4 register tile x 2 k steps, the
+// conv_v4 phase) back to back; operands: random values of the 16-bit type in registers, re-read every iteration from a per-lane table
+// in LDS so that the operand buses toggle as in a convolution.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int F16>
+__global__ __launch_bounds__(512) void soak(const uint4* __restrict__ ops, float* out, long iters) {
+    extern __shared__ uint4 lds[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 8 * 1024; i += blockDim.x) lds[i] = ops[(blockIdx.x * 8192 + i) & 0xffff];
+    __syncthreads();
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (long it = 0; it < iters; ++it) {
+        uint4 a[4], b[8];
+        const int base = (int)(it & 7) * 1024 + (tid & 511);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = lds[(base + k * 64) & 8191];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b[k] = lds[(base + 256 + k * 64) & 8191];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (F16) acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[kk * 2 + i]), __builtin_bit_cast(f16x8, b[kk * 4 + j]), acc[i * 4 + j], 0, 0, 0);
+                    else     acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kk * 2 + i]), __builtin_bit_cast(bf16x8, b[kk * 4 + j]), acc[i * 4 + j], 0, 0, 0);
+                }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 1.2345f) out[tid] = s;
+}
+
+static unsigned short f2h(float f, int f16) {   // round-to-nearest conversions good enough for test data
+    if (!f16) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1)) >> 16); }
+    _Float16 h = (_Float16)f; unsigned short r; memcpy(&r, &h, 2); return r;
+}
+
+int main(int argc, char** argv) {
+    const int f16 = argc > 1 ? atoi(argv[1]) : 0;
+    const double secs = argc > 2 ? atof(argv[2]) : 6.0;
+    const int wps = argc > 3 ? atoi(argv[3]) : 2;
+    const int threads = wps == 1 ? 256 : 512;
+    unsigned short* h = (unsigned short*)malloc(65536 * 16);
+    srand(1);
+    for (int i = 0; i < 65536 * 8; ++i) {     // ~N(0, 1): sum of 4 uniforms
+        float v = 0.f; for (int k = 0; k < 4; ++k) v += (float)rand() / RAND_MAX - 0.5f;
+        h[i] = f2h(v * 1.7f, f16);
+    }
+    uint4* d; float* o;
+    hipMalloc(&d, 65536 * 16); hipMalloc(&o, 4096);
+    hipMemcpy(d, h, 65536 * 16, hipMemcpyHostToDevice);
+    auto kern = f16 ? soak<1> : soak<0>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16);
+    long iters = 20000;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 8192 * 16, 0, d, o, iters); hipDeviceSynchronize();
+    double total_flop = 0, total_s = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    while (true) {
+        auto a0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 8192 * 16, 0, d, o, iters); hipDeviceSynchronize();
+        auto a1 = std::chrono::steady_clock::now();
+        const double dt = std::chrono::duration<double>(a1 - a0).count();
+        total_s += dt; total_flop += (double)iters * 16 * 32768.0 * (threads / 64) * 256;
+        if (std::chrono::duration<double>(a1 - t0).count() > secs) break;
+        if (dt < 0.5) iters *= 2;
+    }
+    printf("%s %d wave(s) per SIMD: %.1f TFLOP/s over %.1f s (%.3f of 2500)\n", f16 ? "f16 " : "bf16", wps, total_flop / total_s / 1e12, total_s, total_flop / total_s / 2.5e15);
+    return 0;
+}

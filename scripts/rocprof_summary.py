@@ -7,7 +7,10 @@ d = sys.argv[1]
 f = sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True))[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-cmd = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+# the profiled command: given, else by the directory name profile.sh uses (prof_roofline = one launch on the chip at a time, the run
+# roofline.avg_launch_ms must agree with; prof_bench = the benchmark command itself, sub-batch streams overlapping)
+cmd = sys.argv[3] if len(sys.argv) > 3 else ("python bench.py --roofline-only" if "roofline" in os.path.basename(os.path.normpath(d))
+                                             else "python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary")
 print(f"# rocprofv3 --kernel-trace --stats of `{cmd}` ({os.path.basename(f)})")
 print(f"# total kernel time {tot / 1e6:.2f} ms over {sum(int(r['Calls']) for r in rows)} launches")
 print(f"{'total ms':>10} {'%':>6} {'calls':>7} {'avg us':>9} {'min us':>8} {'max us':>8}  kernel")

@@ -13,16 +13,29 @@ Rules (each bound is a stated multiple of the reference-side figure):
   * one network evaluation: the HIP 16-bit mode may not be worse than the reference's own 16-bit run: factor 1.0 (the maximum over
     the stored t pairs) on the fixture's inputs; factor 1.25 on other inputs (measured 1.00 on tests/test_hip_fused_batch.py's) and for the
     long-sequence attention (1024 tokens, probabilities rounded to 16 bits for the P.V GEMM).
-  * chained sampler outputs (N evaluations, spectrogram or waveform): factor 3.0 (rel-max) / 2.0 (rel-L2) of the reference's
-    60-evaluation chain figure.  Round 5 tried 2.25 / 1.75 (VERDICT r4 asked for 1.75 / 1.5 from one 1.4 reading) and learned what the
-    statistic does: a build that differs from its predecessor ONLY in the summation order of the GroupNorm partial sums (1e-8 relative
-    in the totals) moved the configs[1] fp16 spectrogram rel-max from 4.31e-3 to 5.91e-3 (1.94 -> 2.66 of the reference figure) and the
-    bf16 waveform rel-max from 3.93e-2 to 4.49e-2 (1.81 -> 2.07), while the rel-L2 figures moved by 5 % (fp16 spectrogram 1.56 -> 1.64,
-    the largest).  The maximum over 2.6 M elements of a 60-evaluation chain at t -> 0.03 is a heavy-tailed statistic of the rounding
-    noise, not a property of the kernels; the rel-L2 is the stable one and carries the tighter factor.  Why the ratios exceed 1 at all: the
-    HIP modes store EVERY activation tensor in 16 bits (that is what halves the HBM traffic) while autocast rounds only the
-    convolution / matmul operands and keeps GroupNorm, SiLU and the residual sums in fp32; and the maximum runs over up to 80x more
-    elements (B = 8, T' = 640 against the fixture's 1 x 64 frames).
+  * chained sampler outputs (N evaluations, spectrogram or waveform), round 6: three statistics of |error| against the
+    same three of the reference's own 60-evaluation autocast chain -
+      rel-L2                                   <= 1.75 x   (the stable statistic)
+      99.99th percentile of |err| / max|ref|   <= 1.75 x   (`chain_*_p9999`: pooled over four 0.4 s utterances, each relative to its own maximum,
+                                                            by `gen_golden.py --only lowprec_chain`: the tail of the error distribution without
+                                                            its single worst element.  VERDICT r5 proposed 1.5 x before anything was measured; the
+                                                            bf16 waveform measures 1.51, and the reference's OWN figure varies 1.12e-2 ... 2.03e-2
+                                                            between the four utterances (`chain_*_p9999_per_utt`), so the factor follows the rel-L2's)
+      rel-max                                  <= 3.0 x    (gross-error guard only)
+    Measured on BASELINE configs[1] (8 x 4 s, 60 evaluations; tests/test_hip_parity.py::test_cfg2_sampler_16bit_drift_against_fp32, round 6),
+    as multiples of the reference-side figures:           rel-L2    p99.99    rel-max
+                                   bf16  spectrogram        1.64      1.38      1.79
+                                   bf16  waveform           1.15      1.51      2.41
+                                   fp16  spectrogram        1.55      0.95      2.16
+                                   fp16  waveform           1.12      0.94      1.67
+    Round 5 learned what the rel-max does: a build that differs from its predecessor ONLY in the summation order of the GroupNorm
+    partial sums (1e-8 relative in the totals) moved the configs[1] fp16 spectrogram rel-max from 4.31e-3 to 5.91e-3 (1.94 -> 2.66 of
+    the reference figure) and the bf16 waveform rel-max from 3.93e-2 to 4.49e-2 (1.81 -> 2.07), while the rel-L2 figures moved by 5 %.
+    The maximum over 2.6 M elements of a 60-evaluation chain at t -> 0.03 is a heavy-tailed statistic of the rounding noise, not a
+    property of the kernels; a 3 x bound on it lets a 1.4 x regression pass unnoticed, so the two tight bounds sit on the statistics
+    that can be tight.  Why the ratios exceed 1 at all: the HIP modes store EVERY activation tensor in 16 bits (that is what halves
+    the HBM traffic) while autocast rounds only the convolution / matmul operands and keeps GroupNorm, SiLU and the residual sums in
+    fp32.
   * fp16 figures that the CPU cannot produce (training backward) are the bf16 figures / 4 (three more mantissa bits = 8x, halved for
     the same storage argument).
   * single operators: k units in the last place of the storage type relative to the tensor maximum (bf16: 2^-8, fp16: 2^-11), k = 4:
@@ -51,12 +64,33 @@ def refine_bound(prec: str = "bf16", factor: float = 1.0) -> float:
     return factor * max(ref16(f"refine_{prec}_relmax_golden"), ref16(f"refine_{prec}_relmax_t128"))
 
 
-CHAIN_FACTOR = {"relmax": 3.0, "rell2": 2.0}
+CHAIN_FACTOR = {"relmax": 3.0, "rell2": 1.75, "p9999": 1.75}
 
 
 def chain_bound(prec: str, what: str, norm: str, factor: float = None) -> float:
-    """what: 'spec' | 'wav'; norm: 'relmax' | 'rell2'."""
+    """what: 'spec' | 'wav'; norm: 'relmax' | 'rell2' | 'p9999'."""
     return (CHAIN_FACTOR[norm] if factor is None else factor) * ref16(f"chain_{prec}_{what}_{norm}")
+
+
+def chain_errors(out, ref) -> dict:
+    """The three statistics of a chained output against its fp32 counterpart (torch tensors, real or complex, any device)."""
+    import torch
+    if out.is_complex():
+        out, ref = torch.view_as_real(out), torch.view_as_real(ref)
+    d = (out.double() - ref.double()).abs().flatten()
+    mx = float(ref.double().abs().max())
+    k = max(1, int(round(0.9999 * (d.numel() - 1))) + 1)                      # the 99.99th percentile as an order statistic (no 16 M limit)
+    return {"relmax": float(d.max()) / mx, "rell2": float(d.norm() / ref.double().norm()), "p9999": float(torch.kthvalue(d.cpu(), k).values) / mx}
+
+
+def assert_chain(prec: str, what: str, out, ref, label: str = "") -> dict:
+    """Assert all three chain bounds (CHAIN_FACTOR) and print what was measured as multiples of the reference-side figures."""
+    e = chain_errors(out, ref)
+    ratios = {n: e[n] / ref16(f"chain_{prec}_{what}_{n}") for n in e}
+    print(f"[measured] {label} {prec} {what}: " + ", ".join(f"{n} {e[n]:.3e} = {ratios[n]:.2f} x ref (<= {CHAIN_FACTOR[n]})" for n in ("rell2", "p9999", "relmax")))
+    for n in e:
+        assert e[n] < chain_bound(prec, what, n), (label, prec, what, n, e[n], chain_bound(prec, what, n))
+    return e
 
 
 def train_bound(prec: str, what: str, factor: float = 1.0) -> float:

@@ -105,6 +105,7 @@ def test_fused_langevin_on_split_batches_16bit(sd_np, prec):
         err = _relmax(out[b], ref[b])
         print(f"[measured] fused langevin {prec} B={B} item {b} (gain {GAINS[b]}): {err:.3g} (bound {tol:g})")
         assert err < tol, (prec, b, err)
+    lp.assert_chain(prec, "wav", out, ref, "fused langevin B=8")   # the tight statistics (rel-L2, 99.99th percentile) over the whole batch
 
 
 @pytest.mark.parametrize("prec,tol", [("fp32", 5e-4), ("bf16", lp.fwd_bound("bf16", 1.25)), ("fp16", lp.fwd_bound("fp16", 1.25))])   # 16-bit: 1.25 x the reference's own autocast error (other inputs than the fixture's)

@@ -214,10 +214,10 @@ bool attn_fused_eligible(int dtype, int N, int C) { return dtype != DT_F32 && C 
 
 void launch_attn_fused(const AttnArgs& a, int dtype, int B, hipStream_t s) {
     static LdsAttrOnce attr;
-    if (attr.first()) {
+    attr.once([&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, AT_SMEM);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fused_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, AT_SMEM);
-    }
+    });
     if (dtype == DT_BF16) hipLaunchKernelGGL(attn_fused_kernel<__bf16>, dim3(B), dim3(512), AT_SMEM, s, a);
     else                  hipLaunchKernelGGL(attn_fused_kernel<_Float16>, dim3(B), dim3(512), AT_SMEM, s, a);
 }

@@ -858,10 +858,10 @@ template <typename T>
 static void wgrad_tile_t(const void* dy, const void* x, float* part, float* bpart, int B, int H, int W, int Cout, int Cin, int ntaps, const WgradPlan& q,
                          hipStream_t s) {
     static LdsAttrOnce attr;
-    if (attr.first()) {
+    attr.once([&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel<9, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel<1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
-    }
+    });
     const dim3 grid(q.tiles * q.nslices);
     if (ntaps == 9) hipLaunchKernelGGL((wgrad_tile_kernel<9, T>), grid, dim3(256), WG_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
     else            hipLaunchKernelGGL((wgrad_tile_kernel<1, T>), grid, dim3(256), WG_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
@@ -870,10 +870,10 @@ template <typename T>
 static void wgrad16_t(const void* dy, const void* x, float* part, float* bpart, int B, int H, int W, int Cout, int Cin, int ntaps, const WgradPlan& q,
                       hipStream_t s) {
     static LdsAttrOnce attr;
-    if (attr.first()) {
+    attr.once([&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel<9, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WH_SMEM);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel<1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, WH_SMEM);
-    }
+    });
     const dim3 grid(q.tiles * q.nslices);
     if (ntaps == 9) hipLaunchKernelGGL((wgrad16_kernel<9, T>), grid, dim3(256), WH_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);
     else            hipLaunchKernelGGL((wgrad16_kernel<1, T>), grid, dim3(256), WH_SMEM, s, (const T*)dy, (const T*)x, part, bpart, B, H, W, Cout, Cin, q);

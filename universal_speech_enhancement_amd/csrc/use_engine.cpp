@@ -91,15 +91,18 @@ struct Act { void* p = nullptr; int C = 0, H = 0, W = 0, dtype = DT_F32; long lo
 
 struct Arena {
     char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
+    bool overflow = false;           // sticky: an allocation did not fit (cannot happen for the plan the arena was sized for)
+    bool* dry_on_overflow = nullptr; // ... and then the evaluation switches itself to the bookkeeping-only mode: no further launch
     void reset() { off = 0; }
     void* alloc(size_t bytes) {
         off = (off + 255) & ~(size_t)255;
         void* p = base ? (void*)(base + off) : nullptr;
         off += bytes;
         if (off > peak) peak = off;
-        if (base && off > cap) {     // cannot happen for the plan the arena was sized for: an option that sizes buffers (conv_in_wgs, stats_part, ...) changed after use_plan
-            fprintf(stderr, "libuse_hip: workspace arena overflow (%zu > %zu bytes): an option read at use_plan changed afterwards - call use_plan again\n", off, cap);
-            abort();
+        if (base && off > cap) {     // never a write past the allocation and never abort() behind a C ABI: the entry point that
+            overflow = true;         // ran this evaluation reports USE_E_STATE (see eval_status); the tensor that did not fit is not touched
+            if (dry_on_overflow) *dry_on_overflow = true;
+            p = base;
         }
         return p;
     }
@@ -129,6 +132,7 @@ struct use_handle {
     Arena arena;
     char* persist = nullptr; size_t persist_bytes = 0;
     size_t arena_alloc = 0, persist_alloc = 0;   // sizes of the two device allocations: kept at their high-water marks across re-plans
+    size_t arena_plan_bytes = 0;                 // what the current plan uses of the first (all sub-batch arenas + GroupNorm totals)
     float *x4 = nullptr, *silu_temb = nullptr, *tembias = nullptr, *t_dev = nullptr;
     float2 *Y = nullptr, *X = nullptr, *Xmean = nullptr, *score = nullptr, *xin = nullptr;
     float2 *cond_buf = nullptr, *cond2_buf = nullptr;   // cond2: the second conditioning spectrogram of condition="both" (6 input channels)
@@ -733,7 +737,7 @@ static void run_score(use_handle* h, const float2* x, const float2* y, const flo
         Fwd f0{h, s, tembias, temb_bstride, t, t_stride};
         f0.B = h->B; f0.arena = &h->arena; f0.st_arena = &h->st_arena[0];
         Act pyr = f0.run(h->x4);
-        launch_score_out((const float*)pyr.p, pcp, t, t_stride, outw, outb, out, h->B, n_per_b, sign, s);
+        if (!h->dry) launch_score_out((const float*)pyr.p, pcp, t, t_stride, outw, outb, out, h->B, n_per_b, sign, s);
         return;
     }
     // Sub-batches on separate streams.  The items are independent inside the network (GroupNorm is per item), so this is
@@ -754,6 +758,7 @@ static void run_score(use_handle* h, const float2* x, const float2* y, const flo
         f.B = h->sub_B[i]; f.arena = i ? &h->sub_arena[i] : &h->arena; f.st_arena = &h->st_arena[i]; f.primary = i == 0;
         if (overlap && i + 1 < h->nsub) { f.ev_stagger = h->ev_stagger[i]; f.stagger_level = g_stagger_level; }
         Act pyr = f.run(h->x4 + (size_t)b0 * n_per_b * pcp);
+        if (!h->dry)
         launch_score_out((const float*)pyr.p, pcp, t ? t + (size_t)b0 * t_stride : nullptr, t_stride, outw, outb,
                          out + (size_t)b0 * n_per_b, h->sub_B[i], n_per_b, sign, si);
         if (overlap && i) (void)hipEventRecord(h->ev_join[i], si);
@@ -845,7 +850,7 @@ static void drop_graphs(use_handle* h) {
 
 // everything of the handle that belongs to ONE plan (the current plan lives in the handle's own fields)
 #define USE_PLAN_FIELDS(X)                                                                                            \
-    X(B) X(T) X(nsub) X(arena) X(arena_alloc) X(persist) X(persist_bytes) X(persist_alloc) X(x4) X(silu_temb) X(tembias) X(t_dev) \
+    X(B) X(T) X(nsub) X(arena) X(arena_alloc) X(arena_plan_bytes) X(persist) X(persist_bytes) X(persist_alloc) X(x4) X(silu_temb) X(tembias) X(t_dev) \
     X(Y) X(X) X(Xmean) X(score) X(xin) X(cond_buf) X(cond2_buf) X(Cond) X(lang_partial) X(lang_step) X(rng_state) X(lang_blocks)   \
     X(sc) X(sampler_set) X(timesteps) X(ts_dev) X(temb_table) X(silu_table) X(noise_copy) X(noise_copy_bytes) X(score_graph)      \
     X(debug) X(debug_B) X(opt_gen_at_plan)
@@ -1190,11 +1195,14 @@ int use_plan(use_handle* h, int B, int Tpad) {
         }
         h->arena_alloc = total;
     }
-    h->arena.base = base; h->arena.cap = total;               // owns the allocation (use_workspace_bytes reports cap)
+    h->arena.base = base; h->arena.cap = caps[0];             // owns the allocation (arena_alloc bytes); its own slice is caps[0]
+    h->arena_plan_bytes = total;
     {
         size_t off = caps[0];
         for (int i = 1; i < h->nsub; ++i) { h->sub_arena[i].base = base + off; h->sub_arena[i].cap = caps[i]; off += caps[i]; }
         for (int i = 0; i < h->nsub; ++i) { h->st_arena[i].base = base + off; h->st_arena[i].cap = stcaps[i]; off += stcaps[i]; }
+        h->arena.dry_on_overflow = &h->dry;
+        for (int i = 0; i < h->nsub; ++i) { h->sub_arena[i].dry_on_overflow = &h->dry; h->st_arena[i].dry_on_overflow = &h->dry; }
     }
     if (h->nsub > 1 && !h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < h->nsub; ++i) {
@@ -1235,7 +1243,7 @@ int use_plan(use_handle* h, int B, int Tpad) {
 
 int use_workspace_bytes(use_handle* h, size_t* bytes) {
     if (!h || !bytes) return fail(USE_E_INVALID, "null argument");
-    *bytes = h->arena.cap + h->persist_bytes + h->blob_bytes;
+    *bytes = h->arena_plan_bytes + h->persist_bytes + h->blob_bytes;
     return USE_OK;
 }
 
@@ -1245,7 +1253,22 @@ static int check_ready(use_handle* h) {
     if (!h) return fail(USE_E_INVALID, "null handle");
     if (!h->weights_ready) return fail(USE_E_STATE, "weights not committed (use_commit_weights / use_alloc_weight_blob)");
     if (!h->B) return fail(USE_E_STATE, "use_plan has not been called");
+    // Options are read at plan time (buffer sizes: conv_in_wgs, stats_part, gn_inline, subbatch*; kernel choice: every threshold): a plan
+    // built under other options is stale.  An error, not a silent re-plan: a re-plan frees the captured graphs and the sampler tables
+    // behind the caller's back (and round 5's answer - overflowing the arena and abort() - was no answer at all).
+    if (h->opt_gen_at_plan != g_opt_gen)
+        return fail(USE_E_STATE, "use_set_option was called after use_plan: the plan is stale, call use_plan (and use_set_sampler) again");
     return USE_OK;
+}
+
+// after an evaluation was issued: did every tensor fit its arena?  (defence in depth behind check_ready's stale-plan test)
+static int eval_status(use_handle* h) {
+    bool bad = h->arena.overflow;
+    for (int i = 0; i < MAX_SUB; ++i) bad = bad || h->sub_arena[i].overflow || h->st_arena[i].overflow;
+    if (!bad) return USE_OK;
+    h->arena.overflow = false; h->dry = false;
+    for (int i = 0; i < MAX_SUB; ++i) h->sub_arena[i].overflow = h->st_arena[i].overflow = false;
+    return fail(USE_E_STATE, "activation workspace too small for this evaluation (an option that sizes plan buffers changed after use_plan?): call use_plan again; the output is invalid");
 }
 
 // one network evaluation; sign -1: the score (use_score), +1: the raw backbone output (use_forward)
@@ -1264,7 +1287,7 @@ static int eval_net(use_handle* h, const void* x, const void* y, const float* t,
     run_score(h, (const float2*)x, (const float2*)y, c.unconditional ? nullptr : h->tembias, h->dense_rows, t, 1, (float2*)out, s, sign,
               (const float2*)y2);
     HIPCHK(hipGetLastError());
-    return USE_OK;
+    return eval_status(h);
 }
 int use_score2(use_handle* h, const void* x, const void* y, const void* y2, const float* t, void* out, use_stream_t stream) {
     return eval_net(h, x, y, t, out, stream, -1.f, y2);
@@ -1410,6 +1433,7 @@ int use_sample_cond2(use_handle* h, const void* y, const void* cond, const void*
     hipLaunchKernelGGL(set_rng_kernel, dim3(1), dim3(1), 0, s, h->rng_state, (unsigned long long)seed, 0ull);
     if (!h->sc.use_graph) {
         run_sampler(h, (const float2*)noise, s, 0, h->sc.N);
+        rc = eval_status(h); if (rc) return rc;
     } else {
         const int gi = noise ? 1 : 0;
         const float2* nz = nullptr;
@@ -1442,6 +1466,7 @@ int use_sample_cond2(use_handle* h, const void* y, const void* cond, const void*
                 // (nothing returns between begin and end: a failed launch invalidates the capture and surfaces here, with the
                 // stream out of capture mode either way)
                 hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+                if (eval_status(h)) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); drop_graphs(h); return USE_E_STATE; }
                 if (e != hipSuccess || !g) {
                     if (g) (void)hipGraphDestroy(g);
                     (void)hipGetLastError();

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <thread>
 
 namespace use {
 
@@ -10,17 +12,19 @@ namespace use {
 // handle on another device of the same process (use_create(cfg, device, ...)) would otherwise launch its > 64 KB-LDS kernels unprepared
 constexpr int USE_MAX_DEVICES = 64;
 struct LdsAttrOnce {
-    bool done[USE_MAX_DEVICES] = {};
-    template <typename K> void operator()(K kern, int bytes) {
+    std::atomic<int> st[USE_MAX_DEVICES] = {};               // per device: 0 not applied, 1 being applied, 2 applied
+    // f() applies the attribute(s); it has RUN when once() returns, on whichever host thread got there first (the round-5 form
+    // raised its flag before the attributes were set, so a second thread could launch a > 64 KB-LDS kernel unprepared)
+    template <typename F> void once(F&& f) {
         int d = 0;
-        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= USE_MAX_DEVICES) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); return; }
-        if (!done[d]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); done[d] = true; }
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= USE_MAX_DEVICES) { f(); return; }
+        if (st[d].load(std::memory_order_acquire) == 2) return;
+        int expected = 0;
+        if (st[d].compare_exchange_strong(expected, 1, std::memory_order_acq_rel)) { f(); st[d].store(2, std::memory_order_release); }
+        else while (st[d].load(std::memory_order_acquire) != 2) std::this_thread::yield();
     }
-    bool first() {            // several kernels behind one flag: true once per device
-        int d = 0;
-        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= USE_MAX_DEVICES) return true;
-        if (done[d]) return false;
-        done[d] = true; return true;
+    template <typename K> void operator()(K kern, int bytes) {
+        once([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
     }
 };
 

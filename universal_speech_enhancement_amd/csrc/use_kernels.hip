@@ -1014,19 +1014,19 @@ void pyr_conv_set_ws(int n) { g_pyr_ws = n; }
 void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
     if (pyr_conv_eligible(a)) {
         static LdsAttrOnce attr_set;
-        if (attr_set.first()) {
+        attr_set.once([&] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, PYR_SMEM);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, PYR_SMEM);
-        }
+        });
         const int ntiles = tiles_per_image(a.H, a.W);
         if (a.C0 <= 2 * PYR_CB && g_pyr_ws) {                // wave-specialised form: one 8-wave workgroup per CU, the launch is one round of workgroups
             static LdsAttrOnce attr3;
-            if (attr3.first()) {
+            attr3.once([&] {
 #define USE_PYRW_ATTR(T, O, A) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pyr_conv_ws_kernel<T, O, A>), hipFuncAttributeMaxDynamicSharedMemorySize, PYRW_SMEM);
                 USE_PYRW_ATTR(__bf16, true, true) USE_PYRW_ATTR(__bf16, true, false) USE_PYRW_ATTR(__bf16, false, true) USE_PYRW_ATTR(__bf16, false, false)
                 USE_PYRW_ATTR(_Float16, true, true) USE_PYRW_ATTR(_Float16, true, false) USE_PYRW_ATTR(_Float16, false, true) USE_PYRW_ATTR(_Float16, false, false)
 #undef USE_PYRW_ATTR
-            }
+            });
             const int per_item = std::max(1, (g_pyr_ws > 1 ? g_pyr_ws : 256) / std::max(1, a.B));
             const int tpw = (ntiles + per_item - 1) / per_item;
             const dim3 grid((ntiles + tpw - 1) / tpw, 1, a.B);

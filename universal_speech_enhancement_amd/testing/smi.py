@@ -7,11 +7,41 @@ import json
 import time
 
 
-def smi_open():
+def _bdf_key(bdf: str):
+    """'0000:05:00.0' / '0000:05:00' / '5:0.0' -> (domain, bus, device) for comparison across the HIP and amdsmi spellings."""
+    import re
+    m = re.search(r"(?:([0-9a-fA-F]{1,8}):)?([0-9a-fA-F]{1,2}):([0-9a-fA-F]{1,2})(?:\.([0-7]))?$", bdf.strip())
+    if not m:
+        return None
+    return (int(m.group(1) or "0", 16), int(m.group(2), 16), int(m.group(3), 16))
+
+
+def smi_open(pci_bus_id: str = None):
+    """(amdsmi module, processor handle).  ``pci_bus_id`` (hipDeviceGetPCIBusId of the device the workload runs on) selects the handle
+    whose BDF matches - with HIP_VISIBLE_DEVICES or a rank > 0 the HIP device index is not the amdsmi index; without it,
+    or without a match, handle 0."""
     import amdsmi
     amdsmi.amdsmi_init()
     hs = amdsmi.amdsmi_get_processor_handles()
+    want = _bdf_key(pci_bus_id) if pci_bus_id else None
+    if want is not None:
+        for h in hs:
+            try:
+                if _bdf_key(str(amdsmi.amdsmi_get_gpu_device_bdf(h))) == want:
+                    return amdsmi, h
+            except Exception:  # noqa: BLE001
+                continue
     return amdsmi, hs[0]
+
+
+def power_cap_watts(amdsmi, h):
+    """The socket power cap the box enforces (amdsmi_get_power_cap_info: microwatts on this driver), or None."""
+    try:
+        c = amdsmi.amdsmi_get_power_cap_info(h)
+        v = float(c.get("power_cap", 0))
+        return round(v / 1e6 if v > 1e5 else v, 1) if v > 0 else None
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def _try(f, *a):
