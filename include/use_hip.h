@@ -168,7 +168,7 @@ int use_istft_back(const void* X, float* wav, int B, int L, int n_fft, int hop, 
                    float exponent, use_stream_t s);
 
 /* Counters of a handle: "graph_captures" (segments of the sampling loop captured so far), "plans_built", "plan_cache_hits",
- * "plans_parked".  A handle keeps the plans - workspace, state, time-embedding tables, captured graphs - of the most recently used
+ * "plans_parked", "plan_stale" (1: use_set_option was called since use_plan - the evaluation entry points will refuse the plan).  A handle keeps the plans - workspace, state, time-embedding tables, captured graphs - of the most recently used
  * (B, T') shapes (use_set_option("plan_cache", k), default 4 besides the current one): use_plan of a parked shape costs nothing and
  * its graphs replay as they are. */
 int use_get_stat(use_handle* h, const char* name, long long* value);

@@ -50,6 +50,32 @@ constexpr bool V4_XF_LEGACY = true;
 constexpr bool V4_XF_LEGACY = false;
 #endif
 
+// Epilogue staging by ds_write_addtid_b32 (round 6; address = M0[15:0] + 16-bit offset + 4 * lane: no address register, 2 LDS-store cycles per
+// wave-instruction against 4 for ds_write_b32 / 6 for ds_write2_b32 - MI355X_MICROARCH.md, LDS: a store's cost is the transfer of its
+// address and data registers; the epilogue's 1 024 staging stores per tile were 4 k of its ~10 k cycles).  M0 holds 16 bits, so a wave
+// stages HALF a round at a time - accumulator registers r = 8 hb ... 8 hb + 7 of its four 32-channel blocks = pixel columns 16 hb ...
+// 16 hb + 15 of its tile row x 128 channels, 8 KB - and the eight regions end below 64 KB.  Register (j, r') is one lane-linear row of 64
+// floats [pixel half h][channel c] at dword j * 512 + r' * 64 + 4 A(j), A(j) = (j & 1) + 8 (j >> 1): the shift by A(j) bank quads makes
+// the read-back conflict-free (a 16-lane group of a ds_read_b128 - lanes {0-3, 12-15, 20-27} etc. - reads one pixel's channel chunks
+// {0-3, 12-15} and its neighbour's {4-11}: bank quad = A(ch >> 2) + 2 (ch & 3) + 8 h + half: 16 distinct values).
+constexpr int v4_stg_off(int r, int j) { return (j * 512 + r * 64 + 4 * ((j & 1) + 8 * (j >> 1))) * 4; }
+constexpr int V4_STG_ATID_BYTES = 8384;                      // (3 * 512 + 7 * 64 + 36 + 64) dwords = 8 336 B, rounded up to 64 bytes
+template <int J, int R0, typename ACC>
+DEVI void v4_stage8(unsigned lds_base, const ACC& a) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[base]\n\ts_nop 0\n\t"
+                 "ds_write_addtid_b32 %[a0] offset:%[o0]\n\tds_write_addtid_b32 %[a1] offset:%[o1]\n\tds_write_addtid_b32 %[a2] offset:%[o2]\n\t"
+                 "ds_write_addtid_b32 %[a3] offset:%[o3]\n\tds_write_addtid_b32 %[a4] offset:%[o4]\n\tds_write_addtid_b32 %[a5] offset:%[o5]\n\t"
+                 "ds_write_addtid_b32 %[a6] offset:%[o6]\n\tds_write_addtid_b32 %[a7] offset:%[o7]\n\t"
+                 "s_mov_b32 m0, %[keep]"
+                 : [keep] "=&s"(keep)
+                 : [base] "s"(lds_base), [a0] "v"(a[R0]), [a1] "v"(a[R0 + 1]), [a2] "v"(a[R0 + 2]), [a3] "v"(a[R0 + 3]), [a4] "v"(a[R0 + 4]),
+                   [a5] "v"(a[R0 + 5]), [a6] "v"(a[R0 + 6]), [a7] "v"(a[R0 + 7]),
+                   [o0] "n"(v4_stg_off(0, J)), [o1] "n"(v4_stg_off(1, J)), [o2] "n"(v4_stg_off(2, J)), [o3] "n"(v4_stg_off(3, J)),
+                   [o4] "n"(v4_stg_off(4, J)), [o5] "n"(v4_stg_off(5, J)), [o6] "n"(v4_stg_off(6, J)), [o7] "n"(v4_stg_off(7, J))
+                 : "memory");
+}
+
 template <typename TIN, typename TOUT, int CK, bool ACT, int EPI>
 __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     typedef Mfma<TIN> MF;
@@ -529,7 +555,8 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     // the accumulators, the multiply by out_scale is skipped when it is 1, and the GroupNorm partial sums are taken from the
     // fp32 values (of which the stored ones are the roundings) instead of re-expanding the packed result.
     constexpr int STG_LD = BN + 4;
-    constexpr int STG_WAVE = 32 * STG_LD * 4;                // 16,896 B per wave and round
+    constexpr bool ATID = EPI >= 0 && !(EPI & 4) && sizeof(TOUT) == 2;   // lane-linear staging of half rounds by ds_write_addtid_b32 (v4_stage8)
+    constexpr int STG_WAVE = ATID ? V4_STG_ATID_BYTES : 32 * STG_LD * 4;   // 8,384 B per wave and half round / 16,896 B per wave and round
     constexpr int CH = 16 / (int)sizeof(TOUT);
     constexpr int CPR = BN / CH;                             // 16-byte chunks per pixel row: 16 (bf16) / 32 (fp32)
     constexpr int QN = 32 * CPR / 64;                        // passes per round: 8 / 16
@@ -556,7 +583,6 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     const bool has_res = EPI_RT ? p.res != nullptr : (EPI & 1) != 0;
     const bool has_scale = EPI_RT ? p.out_scale != 1.f : (EPI & 2) != 0;
     const bool has_pyr = EPI_RT ? p.pyr != nullptr : (EPI & 4) != 0;
-    constexpr bool PIPE = EPI >= 0 && !(EPI & 4) && sizeof(TOUT) == 2;   // round 1 staged behind round 0's reads (registers: not with the Combine set)
     constexpr bool HOIST_W4 = sizeof(TOUT) == 2;             // fp32 parity kernels: no registers to spare, in-loop loads
     // Combine ('sum') weights of this lane's channels: loop-invariant, fetched once (they were re-read per pixel piece)
     float4 w4r[CH]; float b4r[CH];
@@ -570,11 +596,13 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     f32x2 st_s2[CH / 2], st_q2[CH / 2];                      // running (sum, sum of squares) of this lane's channels, as pairs
 #pragma unroll
     for (int k = 0; k < CH / 2; ++k) { st_s2[k] = (f32x2){0.f, 0.f}; st_q2[k] = (f32x2){0.f, 0.f}; }
-    // (staging by ds_write_addtid_b32 - lane-linear rows, no address register, half the LDS-store cycles - was tried here in round 6: its
-    // base is M0[15:0], the eight waves' 16.5 KB regions reach past 64 KB, and the lone-launch stamps showed the rounds are not what
-    // bounds the epilogue anyway: the drain of the tile's 128 KB of output stores is)
-    const float* const stg_rd = stg + (lane / CPR) * STG_LD + ch * CH;       // pass q, 16-byte half c4: + q * PPP * STG_LD + 4 c4
-    auto stg_rd_off = [&](int q, int c4) -> int { return q * PPP * STG_LD + c4 * 4; };
+    // read-back address of pass q (pixel column x = q * PPP + lane / CPR of the round's tile row, channels ch * CH ...), 16-byte half c4:
+    //   padded rows:  stg[x][ch * CH + 4 c4]
+    //   add-TID form (half rounds of 16 columns, q = 0 .. 3 inside one): x = (r & 3) + 8 (r >> 2) + 4 h  ->  r' = lane / 16 + 4 (q >> 1), h = q & 1
+    const float* const stg_rd = ATID ? stg + (ch >> 2) * 512 + (lane >> 4) * 64 + 4 * (((ch >> 2) & 1) + 8 * (ch >> 3)) + (ch & 3) * 8
+                                     : stg + (lane / CPR) * STG_LD + ch * CH;
+    auto stg_rd_off = [&](int q, int c4) -> int { return ATID ? ((q >> 1) & 1) * 256 + (q & 1) * 32 + c4 * 4 : q * PPP * STG_LD + c4 * 4; };   // floats
+    const unsigned stg_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)(wave_u * STG_WAVE);
     auto row_bytes = [&](int i) -> unsigned {                // byte offset of this wave's tile row i inside the image (uniform)
         return (unsigned)(((ty0 + wave_u * 2 + i) * p.W + tx0) * p.Cout) * (unsigned)sizeof(TOUT);
     };
@@ -595,7 +623,11 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
     };
     // passes read back / finished together: all of a round (specialised forms), a quarter of a round with the Combine set (its weights take 40
     // registers), one at a time with run-time flags (fp32 parity kernels: 16 passes of a round would not fit the register file)
-    constexpr int NQ = EPI_RT ? 1 : (EPI & 4) ? QN / 4 : QN;
+    constexpr int NQ = EPI_RT ? 1 : (EPI & 4) ? QN / 4 : ATID ? QN / 2 : QN;
+    auto stage_write_half = [&](int i, int hb) {             // add-TID form: pixel columns 16 hb ... 16 hb + 15 of tile row i
+        if (hb == 0) { v4_stage8<0, 0>(stg_lds, acc[i][0]); v4_stage8<1, 0>(stg_lds, acc[i][1]); v4_stage8<2, 0>(stg_lds, acc[i][2]); v4_stage8<3, 0>(stg_lds, acc[i][3]); }
+        else         { v4_stage8<0, 8>(stg_lds, acc[i][0]); v4_stage8<1, 8>(stg_lds, acc[i][1]); v4_stage8<2, 8>(stg_lds, acc[i][2]); v4_stage8<3, 8>(stg_lds, acc[i][3]); }
+    };
     auto stage_read = [&](int q0, f32x4 (&t)[NQ][CH / 4]) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
@@ -661,30 +693,34 @@ __global__ __launch_bounds__(512) void conv_v4_kernel(ConvArgs p) {
         uint4 rv0[QN], rv1[QN];
         f32x4 t[NQ][CH / 4];
         if (has_res) res_load(0, rv0);
-        stage_write(0);
-        __builtin_amdgcn_wave_barrier();
-        if constexpr (PIPE) {
+        if constexpr (ATID) {
             // Left alone, LLVM puts every read back in front of its pass and pulls the passes' arithmetic up between the reads (pure
             // arithmetic is ordered by nothing - not by sched_barrier, not by a memory clobber).  The pieces therefore pass through an
-            // empty volatile asm as in/out operands: everything computed from them follows it, all reads precede it.
+            // empty volatile asm as in/out operands: everything computed from them follows it, all reads precede it.  A half round's
+            // staging stores are issued behind the previous half round's reads (DS operations of one wave execute in order).
+            static_assert(NQ * (CH / 4) == 8 && QN == 8, "8 pieces per half round");
             auto pin = [&]() {
-                static_assert(NQ * (CH / 4) == 16, "16 pieces per round");
-                asm volatile("" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[3][0]), "+v"(t[3][1]),
-                                  "+v"(t[4][0]), "+v"(t[4][1]), "+v"(t[5][0]), "+v"(t[5][1]), "+v"(t[6][0]), "+v"(t[6][1]), "+v"(t[7][0]), "+v"(t[7][1]) :: "memory");
+                asm volatile("" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[3][0]), "+v"(t[3][1]) :: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             };
-            stage_read(0, t);
-            if (has_res) res_load(1, rv1);
-            pin();
-            stage_write(1);                                  // behind the reads above in this wave's DS queue
-            asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-            finish(0, 0, t, rv0);
+            auto fence = [&]() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+            stage_write_half(0, 0);
+            stage_read(0, t); if (has_res) res_load(1, rv1); pin();
+            stage_write_half(0, 1); fence();
+            finish(0, 0, t, rv0); fence();
+            stage_read(NQ, t); pin();
+            stage_write_half(1, 0); fence();
+            finish(0, NQ, t, rv0);
             V4_STAMP(7)
-            asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-            stage_read(0, t);
-            pin();
-            finish(1, 0, t, rv1);
+            fence();
+            stage_read(0, t); pin();
+            stage_write_half(1, 1); fence();
+            finish(1, 0, t, rv1); fence();
+            stage_read(NQ, t); pin();
+            finish(1, NQ, t, rv1);
         } else {
+            stage_write(0);
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int q0 = 0; q0 < QN; q0 += NQ) { stage_read(q0, t); finish(0, q0, t, rv0); }
             V4_STAMP(7)
@@ -794,9 +830,15 @@ void launch_conv_v4(const ConvArgs& a0, hipStream_t s) {
         static int printed = 0;
         static unsigned long long* trace_buf = nullptr;
         if (!trace_buf) (void)hipMalloc((void**)&trace_buf, 512 * 8);
-        if (!printed && a.H == 512 && a.C0 + a.C1 == atoi(getenv("USE_HIP_TRACE")) && a.in_dtype == DT_BF16) {
+        // USE_HIP_TRACE_SKIP=n: the (n + 1)-th matching launch (a launch in the middle of a multi-stream evaluation, with the other sub-batches'
+        // kernels on the chip); USE_HIP_TRACE_WG=w: the workgroup that stamps (index blockIdx.x + gridDim.x * item)
+        static int skip = getenv("USE_HIP_TRACE_SKIP") ? atoi(getenv("USE_HIP_TRACE_SKIP")) : 0;
+        const bool match = a.H == 512 && a.C0 + a.C1 == atoi(getenv("USE_HIP_TRACE")) && a.in_dtype == DT_BF16 &&
+                           (!getenv("USE_HIP_TRACE_RES") || (a.res != nullptr) == (atoi(getenv("USE_HIP_TRACE_RES")) != 0));
+        if (!printed && match && skip-- <= 0) {
             (void)hipMemsetAsync(trace_buf, 0, 512 * 8, s);
             a.trace = trace_buf;
+            if (getenv("USE_HIP_TRACE_WG")) a.dbg = atoi(getenv("USE_HIP_TRACE_WG"));
             a.act ? v4_launch_t<__bf16, __bf16, 32, true>(a, s) : v4_launch_t<__bf16, __bf16, 32, false>(a, s);
             (void)hipStreamSynchronize(s);
             unsigned long long hbuf[512];
@@ -809,7 +851,7 @@ void launch_conv_v4(const ConvArgs& a0, hipStream_t s) {
                 }
             }
             printed = 1;
-            a.trace = nullptr;
+            a.trace = nullptr; a.dbg = a0.dbg;
         }
     }
 #endif

@@ -925,6 +925,7 @@ int use_get_stat(use_handle* h, const char* name, long long* value) {
     if (!strcmp(name, "plans_built")) { *value = h->n_plans_built; return USE_OK; }
     if (!strcmp(name, "plan_cache_hits")) { *value = h->n_plan_cache_hits; return USE_OK; }
     if (!strcmp(name, "plans_parked")) { *value = (long long)h->plan_cache.size(); return USE_OK; }
+    if (!strcmp(name, "plan_stale")) { *value = h->B && h->opt_gen_at_plan != g_opt_gen ? 1 : 0; return USE_OK; }   // an option changed since use_plan
     return fail(USE_E_INVALID, "unknown statistic '%s'", name);
 }
 

@@ -184,7 +184,8 @@ class HipScoreEngine:
 
     # ---- planning -----------------------------------------------------------------------------------
     def plan(self, B: int, Tpad: int):
-        if self.plan_shape != (B, Tpad):
+        # (options are read at use_plan: after a use_set_option the C entry points refuse the stale plan with USE_E_STATE - re-plan here)
+        if self.plan_shape != (B, Tpad) or self.stat("plan_stale"):
             check(self.L.use_plan(self.h, B, Tpad), "use_plan")
             self.plan_shape = (B, Tpad)
             self.sampler_key = None
