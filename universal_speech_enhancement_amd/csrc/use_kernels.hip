@@ -820,18 +820,25 @@ __global__ __launch_bounds__(256) void conv_in_kernel(ConvArgs p) {
 // weight operand comes pre-split from the blob (ConvArgs::wb, pack_conv_in_split); the fp32 parity mode keeps conv_in_kernel.
 constexpr int CINS_WP = CONV_IN_SPLIT_K * 2 + 16;            // weight row pitch in LDS (bytes): 240 = 15 x 16, conflict-free b128 reads
 constexpr int CINS_XB = (TILE_H + 2) * (TILE_W + 2) * 8;     // one halo array: [180 px][4] bf16
-constexpr int CINS_SP = 72;                                  // staging row pitch (floats) of a 32-pixel x 64-channel half tile
 // A workgroup walks `tiles_per_wg` consecutive tiles of one item: the weights are staged once, and the GroupNorm totals leave as ONE
 // pair of atomics per channel per workgroup -- with a workgroup per tile the 2560 tiles of a 512x640 map queue 2560 deep on each of
 // the item's 256 totals, and that queue, not the arithmetic or the stores, set the kernel's duration (326 us).
-template <typename TOUT>
+// Round 6: the epilogue follows conv_v4's (use_conv_v4.hip): a wave's 32 pixels x 128 channels leave in two halves (its two tile rows), each staged
+// by 32 ds_write_addtid_b32 (lane-linear rows, half the LDS-store cycles of ds_write_b32, v4_stage8), read back as eight conflict-free
+// ds_read_b128 up front and finished in four straight-line passes (pack, 16-byte store of 4 pixels x 256 B, statistics on channel pairs);
+// FULL (whole tiles, whole 128-channel block: every shipped shape) drops the masks.  The statistics are taken from the fp32 values the
+// stored ones are the roundings of, as in conv_v4.  77 -> see profiles/r6_conv_in_addtid.txt.
+template <typename TOUT, bool FULL>
 __global__ __launch_bounds__(256) void conv_in_split_kernel(ConvArgs p, int tiles_per_wg) {
     static_assert(sizeof(TOUT) == 2, "16-bit storage modes only");
     constexpr int HALO = (TILE_H + 2) * (TILE_W + 2);
-    __shared__ __attribute__((aligned(16))) char s_x[3 * CINS_XB];           // [xh | xl | zeros], each [180][4] bf16
-    __shared__ __attribute__((aligned(16))) char s_w[128 * CINS_WP];         // [128 co][112 (+8)] bf16
-    __shared__ __attribute__((aligned(16))) float s_stg[4 * 32 * CINS_SP];   // per wave: [32 px][64 (+8)] fp32
-    __shared__ float s_red[4 * 128 * 2];
+    // one block, carved by hand: the staging regions first (ds_write_addtid_b32 takes its base from M0[15:0])
+    constexpr int O_STG = 0, O_X = O_STG + 4 * V4_STG_ATID_BYTES, O_W = O_X + 3 * CINS_XB, O_RED = O_W + 128 * CINS_WP, SM_BYTES = O_RED + 4 * 128 * 2 * 4;
+    static_assert(O_X % 16 == 0 && O_W % 16 == 0 && O_RED % 16 == 0 && SM_BYTES <= 80 * 1024, "LDS layout (two workgroups per CU)");
+    __shared__ __attribute__((aligned(64))) char s_all[SM_BYTES];
+    char* const s_x = s_all + O_X;                            // [xh | xl | zeros], each [180][4] bf16
+    char* const s_w = s_all + O_W;                            // [128 co][112 (+8)] bf16
+    float* const s_red = reinterpret_cast<float*>(s_all + O_RED);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z;
     const int tiles_x = (p.W + TILE_W - 1) / TILE_W, ntiles = tiles_x * ((p.H + TILE_H - 1) / TILE_H);
@@ -848,17 +855,19 @@ __global__ __launch_bounds__(256) void conv_in_split_kernel(ConvArgs p, int tile
     const int m = lane & 31, hlf = lane >> 5;
     const char* const pa = s_x + ((wave * 2 + (m >> 4)) * (TILE_W + 2) + (m & 15)) * 8;
     const char* const pb = s_w + m * CINS_WP + hlf * 16;
-    float* const stg = s_stg + wave * (32 * CINS_SP);
-    constexpr int CH = 8, CPR = 8, PPQ = 8;                   // 16-byte chunks: 8 channels; 8 chunks per half-tile row; 8 pixels per pass
-    const int ch = lane % CPR;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned stg_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_all + (unsigned)(O_STG + wave_u * V4_STG_ATID_BYTES);
+    constexpr int CH = 8;                                     // 16-byte chunks of 8 channels; lane -> (pixel lane / 16 of a pass, chunk lane % 16)
+    const int ch = lane & 15, p4 = lane >> 4;
+    // read-back address (use_device.h, v4_stage8): pass q of a half -> tile column x = 4 q + p4: register r' = p4 + 4 (q >> 1), lane half h = q & 1
+    const float* const stg_rd = reinterpret_cast<const float*>(s_all + O_STG + wave * V4_STG_ATID_BYTES) + (ch >> 2) * 512 + p4 * 64 +
+                                4 * (((ch >> 2) & 1) + 8 * (ch >> 3)) + (ch & 3) * 8;
     float bias[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int co = n0 + j * 32 + m; bias[j] = (co < p.Cout && p.bias) ? p.bias[co] : 0.f; }
-    float st_s[2][CH], st_q[2][CH];
+    f32x2 st_s2[CH / 2], st_q2[CH / 2];
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int c = 0; c < CH; ++c) { st_s[h2][c] = 0.f; st_q[h2][c] = 0.f; }
+    for (int k = 0; k < CH / 2; ++k) { st_s2[k] = (f32x2){0.f, 0.f}; st_q2[k] = (f32x2){0.f, 0.f}; }
     TOUT* out = (TOUT*)p.out;
     const int t_end = min(ntiles, ((int)blockIdx.x + 1) * tiles_per_wg);
     // Round 5: the halo of tile t + 1 (one 16-byte pixel per thread, 180 of 256 threads) is requested right after tile t's halo is in LDS and
@@ -876,6 +885,11 @@ __global__ __launch_bounds__(256) void conv_in_split_kernel(ConvArgs p, int tile
         const bool inb = tid < HALO && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, inb ? (unsigned)(gy * p.W + gx) * 16u : 0xfffffff0u, 0, 0));
     };
+    const int co0 = n0 + ch * CH;
+    const bool cok = FULL || co0 < p.Cout;
+    const unsigned voff = cok ? (unsigned)((p4 * p.Cout + co0) * 2) : 0x80000000u;            // lane part of a store offset (beyond Cout: out of range)
+    const unsigned pass_b = (unsigned)(4 * p.Cout * 2);                                      // 4 pixels per pass
+    const bool scaled = p.out_scale != 1.f;                   // (1 for the network's input convolution)
     float4 hv = halo_ld(min((int)blockIdx.x * tiles_per_wg, ntiles - 1));
     for (int tile = blockIdx.x * tiles_per_wg; tile < t_end; ++tile) {
         const int ty0 = (tile / tiles_x) * TILE_H, tx0 = (tile % tiles_x) * TILE_W;
@@ -910,53 +924,63 @@ __global__ __launch_bounds__(256) void conv_in_split_kernel(ConvArgs p, int tile
             for (int j = 0; j < 4; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, *reinterpret_cast<const bf16x8*>(pb + j * 32 * CINS_WP + s * 32), acc[j], 0, 0, 0);
         }
-        // epilogue, per wave, 64 channels at a time through its own staging: 16-byte stores, 128 contiguous bytes per pixel
+        if (scaled) {
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+                for (int r = 0; r < 16; ++r) acc[j][r] *= p.out_scale;
+        }
+        // epilogue: the wave's two tile rows (16 pixels x 128 channels each) one after the other
+        const unsigned tile_b = (unsigned)((((ty0 + wave_u * 2) * p.W + tx0) * p.Cout) * 2);     // (uniform)
+        const unsigned rowp_b = (unsigned)(p.W * p.Cout * 2);
+        f32x4 t[4][2];
+        auto pin = [&]() {
+            asm volatile("" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[3][0]), "+v"(t[3][1]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto read_half = [&]() {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    stg[row * CINS_SP + jj * 32 + m] = acc[h2 * 2 + jj][r] * p.out_scale;
-                }
-            __builtin_amdgcn_wave_barrier();
-            const int co0 = n0 + h2 * 64 + ch * CH;
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int q = 0; q < 32 / PPQ; ++q) {
-                const int row = q * PPQ + lane / CPR;
-                const int gy = ty0 + wave * 2 + (row >> 4), gx = tx0 + (row & 15);
-                const bool ok = co0 < p.Cout && gy < p.H && gx < p.W;
-                float v[CH];
+                for (int c4 = 0; c4 < 2; ++c4) t[q][c4] = *reinterpret_cast<const f32x4*>(stg_rd + (q >> 1) * 256 + (q & 1) * 32 + c4 * 4);
+        };
+        auto finish_half = [&](int hb) {
+            const int gy = ty0 + wave_u * 2 + hb;
 #pragma unroll
-                for (int c4 = 0; c4 < CH / 4; ++c4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(stg + row * CINS_SP + ch * CH + c4 * 4);
-                    v[c4 * 4] = t4.x; v[c4 * 4 + 1] = t4.y; v[c4 * 4 + 2] = t4.z; v[c4 * 4 + 3] = t4.w;
-                }
+            for (int q = 0; q < 4; ++q) {
+                const bool ok = FULL || (cok && gy < p.H && tx0 + q * 4 + p4 < p.W);
+                float v[CH] = {t[q][0].x, t[q][0].y, t[q][0].z, t[q][0].w, t[q][1].x, t[q][1].y, t[q][1].z, t[q][1].w};
                 const uint4 packed = Vec16<TOUT>::pack(v);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, packed), rs_o,
-                                                       ok ? (unsigned)((gy * p.W + gx) * p.Cout + co0) * 2u : 0xfffffff0u, 0, 0);
+                                                       ok ? voff + tile_b + (unsigned)hb * rowp_b + (unsigned)q * pass_b : 0x80000000u, 0, 0);
                 if (ok) {
-                    float vr[CH];
-                    Vec16<TOUT>::load(reinterpret_cast<const TOUT*>(&packed), vr);       // statistics of the stored values
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) { st_s[h2][c] += vr[c]; st_q[h2][c] += vr[c] * vr[c]; }
+                    for (int k = 0; k < CH / 2; ++k) {
+                        const f32x2 x = {v[2 * k], v[2 * k + 1]};
+                        st_s2[k] += x; st_q2[k] = __builtin_elementwise_fma(x, x, st_q2[k]);
+                    }
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-        }
+        };
+        v4_stage8<0, 0>(stg_lds, acc[0]); v4_stage8<1, 0>(stg_lds, acc[1]); v4_stage8<2, 0>(stg_lds, acc[2]); v4_stage8<3, 0>(stg_lds, acc[3]);
+        read_half(); pin();
+        v4_stage8<0, 8>(stg_lds, acc[0]); v4_stage8<1, 8>(stg_lds, acc[1]); v4_stage8<2, 8>(stg_lds, acc[2]); v4_stage8<3, 8>(stg_lds, acc[3]);
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+        finish_half(0);
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+        read_half(); pin();
+        finish_half(1);
         LDS_BARRIER();                                          // every wave is done with this tile's halo (LDS-only: no wait for the stores' acknowledgement)
     }
     if (p.stats || p.stats_part) {
+        // lanes holding the same channel chunk are 16 apart
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c) { st_s[h2][c] = reduce_lanes_stride<CPR>(st_s[h2][c]); st_q[h2][c] = reduce_lanes_stride<CPR>(st_q[h2][c]); }
-            if (lane < CPR) {
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    s_red[(wave * 128 + h2 * 64 + ch * CH + c) * 2] = st_s[h2][c]; s_red[(wave * 128 + h2 * 64 + ch * CH + c) * 2 + 1] = st_q[h2][c];
-                }
+        for (int k = 0; k < CH / 2; ++k) {
+            const float s0 = reduce_lanes_stride<16>(st_s2[k].x), s1 = reduce_lanes_stride<16>(st_s2[k].y);
+            const float q0 = reduce_lanes_stride<16>(st_q2[k].x), q1 = reduce_lanes_stride<16>(st_q2[k].y);
+            if (lane < 16) {
+                s_red[(wave * 128 + ch * CH + 2 * k) * 2] = s0; s_red[(wave * 128 + ch * CH + 2 * k) * 2 + 1] = q0;
+                s_red[(wave * 128 + ch * CH + 2 * k + 1) * 2] = s1; s_red[(wave * 128 + ch * CH + 2 * k + 1) * 2 + 1] = q1;
             }
         }
         __syncthreads();
@@ -1047,10 +1071,14 @@ void launch_conv_generic(const ConvArgs& a, hipStream_t s) {
         dim3 grid(tiles_per_image(a.H, a.W), (a.Cout + 127) / 128, a.B);
         const int tpw = conv_in_split_tpw(a.H, a.W);
         dim3 grid_s(conv_in_split_wgs(a.H, a.W), (a.Cout + 127) / 128, a.B);
-        if (a.out_dtype == DT_BF16)     { if (a.wb) hipLaunchKernelGGL((conv_in_split_kernel<__bf16>), grid_s, dim3(256), 0, s, a, tpw);
+        const bool full = a.H % TILE_H == 0 && a.W % TILE_W == 0 && a.Cout % 128 == 0;      // whole tiles, whole channel blocks: no masks in the epilogue
+#define USE_CINS_GO(T) { if (full) hipLaunchKernelGGL((conv_in_split_kernel<T, true>), grid_s, dim3(256), 0, s, a, tpw); \
+                         else hipLaunchKernelGGL((conv_in_split_kernel<T, false>), grid_s, dim3(256), 0, s, a, tpw); }
+        if (a.out_dtype == DT_BF16)     { if (a.wb) USE_CINS_GO(__bf16)
                                           else      hipLaunchKernelGGL((conv_in_kernel<__bf16>), grid, dim3(256), 0, s, a); }
-        else if (a.out_dtype == DT_F16) { if (a.wb) hipLaunchKernelGGL((conv_in_split_kernel<_Float16>), grid_s, dim3(256), 0, s, a, tpw);
+        else if (a.out_dtype == DT_F16) { if (a.wb) USE_CINS_GO(_Float16)
                                           else      hipLaunchKernelGGL((conv_in_kernel<_Float16>), grid, dim3(256), 0, s, a); }
+#undef USE_CINS_GO
         else                            hipLaunchKernelGGL((conv_in_kernel<float>), grid, dim3(256), 0, s, a);
         return;
     }
