@@ -501,8 +501,14 @@ struct Fwd {
         const float* coef_arr = (gn && (long)a.H * a.W > g_gn_inline) ? gn_coef(a, a2, *gn) : nullptr;
         // Large maps: the producer writes per-workgroup partial totals instead of queueing 640 atomics per item on each total; every consumer
         // of such a map goes through gn_coef (same threshold), which sums them.  (allocated in the dry run as well: the arena is sized by it)
-        long long* part = (stats && g_stats_part && (long)a.H * a.W > g_gn_inline)
-                              ? (long long*)arena->alloc((size_t)B * std::max(conv_v4_tiles(a.H, a.W), std::max(256, g_conv_in_wgs)) * w.cout * 2 * sizeof(long long)) : nullptr;
+        // Only for the two launch shapes that can write them (pointer-free test, so that the dry run sizes the arena like the real one):
+        // the input convolution's walk (conv_in_split_wgs workgroups per item) and conv_v4's tile grid (the buffer used to be
+        // max(tiles, 256, conv_in_wgs) rows for every stats-producing convolution of a large map, whatever kernel ran it).
+        const bool in_shape = a.dtype == DT_F32 && w.cin <= 8 && w.ntaps == 9 && out_dtype != DT_F32;
+        const bool v4_shape = w.ntaps == 9 && w.cout > 32 && a.dtype == out_dtype && a.H % 16 == 0 && a.W % 32 == 0;
+        const int part_rows = in_shape ? conv_in_split_wgs(a.H, a.W) : v4_shape ? conv_v4_tiles(a.H, a.W) : 0;
+        long long* part = (stats && g_stats_part && part_rows > 0 && (long)a.H * a.W > g_gn_inline)
+                              ? (long long*)arena->alloc((size_t)B * part_rows * w.cout * 2 * sizeof(long long)) : nullptr;
         if (h->dry) return o;
         ConvArgs p{};
         p.src0 = a.p; p.C0 = a.C; p.src1 = a2 ? a2->p : nullptr; p.C1 = a2 ? a2->C : 0; p.in_dtype = a.dtype;
@@ -523,7 +529,12 @@ struct Fwd {
         p.out = o.p; p.out_dtype = out_dtype; p.stats = o.stats;
         p.B = B; p.H = a.H; p.W = a.W; p.Cout = w.cout; p.ntaps = w.ntaps;
         const bool main_variant = conv_v4_eligible(p);        // the dominant kernel (conv_v4_kernel, large maps)
-        if (const int nparts = part ? conv_stats_parts(p) : 0) { p.stats_part = part; p.stats = nullptr; o.part = part; o.ntiles = nparts; }
+        if (const int nparts = part ? conv_stats_parts(p) : 0) {
+            if (nparts <= part_rows) { p.stats_part = part; p.stats = nullptr; o.part = part; o.ntiles = nparts; }   // (else: atomics; cannot happen, both count the same grid)
+        }
+        // consumers that read the totals directly (inline GroupNorm below gn_inline pixels, the fused attention) must never meet a producer
+        // that wrote partial totals instead: both sides test the same H * W > gn_inline - checked here, where the input is consumed
+        if (gn && !coef_arr && (a.part || (a2 && a2->part))) { arena->overflow = true; h->dry = true; return o; }   // reported by eval_status as a stale plan
         if (h->profile && (main_variant || (h->profile_all && conv_v2_eligible(p)))) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0, s);
@@ -592,6 +603,7 @@ struct Fwd {
             Act o = new_act(x.C, x.H, x.W, dt, true);
             h->flops += 4.0 * 2.0 * B * x.H * x.W * (double)x.C * x.C;                  // the four NIN, as the unfused path counts them
             if (h->dry) return o;
+            if (x.part) { arena->overflow = true; h->dry = true; return o; }   // (the fused block reads x.stats: a producer with partial totals cannot feed it)
             AttnArgs a{};
             a.x = x.p; a.out = o.p; a.N = x.H * x.W;
             a.gn_st = x.stats; a.gn_gamma = W<float>(aw.gn.g_off); a.gn_beta = W<float>(aw.gn.b_off); a.gn_groups = std::min(x.C / 4, 32); a.gn_eps = 1e-6f;
