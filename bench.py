@@ -351,7 +351,7 @@ def main():
     if a.precision == "bf16" and (B, Tp) == (8, 640):   # the PMC passes were collected on exactly this workload
         import glob
         import hashlib
-        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv_v4.json")), key=lambda f: (int(os.path.basename(f).split("_")[0][1:] or 0), f))
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv_v[45].json")), key=lambda f: (int(os.path.basename(f).split("_")[0][1:] or 0), f))
         if pm:
             rec = json.load(open(pm[-1]))
             src = os.path.join(ROOT, rec.get("kernel_source", "universal_speech_enhancement_amd/csrc/use_conv_v4.hip"))
@@ -365,7 +365,9 @@ def main():
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_source": traffic_src,
                 "algorithmic_hbm_bytes_per_launch": round(conv_bytes / max(conv_launches, 1)),
-                "kernel": "use::conv_v4_kernel<%s> (wide-tile implicit-GEMM 3x3 conv of the large maps, both ACT variants)"
+                # 16-bit storage: conv_v5_kernel (round 6: conv_v4's tile and pipeline on v_mfma_f32_16x16x32, less energy per FLOP); fp32: conv_v4_kernel
+                "kernel": ("use::conv_v5_kernel<%s> (wide-tile implicit-GEMM 3x3 conv of the large maps on 16x16x32 MFMAs, both ACT variants, five epilogue forms)"
+                           if a.precision != "fp32" else "use::conv_v4_kernel<%s> (wide-tile implicit-GEMM 3x3 conv of the large maps, both ACT variants)")
                           % ({"bf16": "bf16,bf16,32", "fp16": "f16,f16,32"}.get(a.precision, "f32,f32,16")),
                 "measured": "HIP events around every launch of one eager score evaluation with the sub-batches run back to back "
                             "(one launch on the chip at a time; `rocprofv3 --stats -- python bench.py --roofline-only` agrees); in "

@@ -7,5 +7,5 @@ R=$(cd "$(dirname "$0")/.." && pwd); C=$R/universal_speech_enhancement_amd/csrc;
 mkdir -p $R/build_ab
 make -s -C $C -j8 >/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c $C/$F.hip -o $R/build_ab/variant_$N.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A8 "conv_v4_kernelIDF16bS0_Li32ELb1E\|error" | grep -i "error\|VGPRs:\|Spill\|LDS Size" | head -8 || true
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_ab/libuse_hip_$N.so $(for o in use_kernels use_conv_v2 use_conv_v4 use_attn use_bwd use_conv_sk use_engine use_io; do if [ $o = $F ]; then echo $R/build_ab/variant_$N.o; else echo $C/$o.o; fi; done)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_ab/libuse_hip_$N.so $(for o in use_kernels use_conv_v2 use_conv_v4 use_conv_v5 use_attn use_bwd use_conv_sk use_engine use_io; do if [ $o = $F ]; then echo $R/build_ab/variant_$N.o; else echo $C/$o.o; fi; done)
 rm -f $R/build_ab/variant_$N.o; ls -la $R/build_ab/libuse_hip_$N.so

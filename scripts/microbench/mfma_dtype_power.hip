@@ -14,8 +14,39 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+// mode 2: v_mfma_f32_16x16x32_bf16 (half the FLOPs per instruction, a quarter of the accumulator registers): 32 independent accumulators,
+// the same twelve 16-byte operand registers per iteration
+__global__ __launch_bounds__(512) void soak16(const uint4* __restrict__ ops, float* out, long iters, int nap) {
+    extern __shared__ uint4 lds[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 8 * 1024; i += blockDim.x) lds[i] = ops[(blockIdx.x * 8192 + i) & 0xffff];
+    __syncthreads();
+    f32x4 acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (long it = 0; it < iters; ++it) {
+        uint4 a[4], b[8];
+        const int base = (int)(it & 7) * 1024 + (tid & 511);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = lds[(base + k * 64) & 8191];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b[k] = lds[(base + 256 + k * 64) & 8191];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[i * 8 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i * 8 + j], 0, 0, 0);
+        for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(4);     // idle 256 cycles per unit: a convolution's matrix duty instead of 100 %
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 1.2345f) out[tid] = s;
+}
+
 template <int F16>
-__global__ __launch_bounds__(512) void soak(const uint4* __restrict__ ops, float* out, long iters) {
+__global__ __launch_bounds__(512) void soak(const uint4* __restrict__ ops, float* out, long iters, int nap) {
     extern __shared__ uint4 lds[];
     const int tid = threadIdx.x;
     for (int i = tid; i < 8 * 1024; i += blockDim.x) lds[i] = ops[(blockIdx.x * 8192 + i) & 0xffff];
@@ -41,6 +72,7 @@ __global__ __launch_bounds__(512) void soak(const uint4* __restrict__ ops, float
                     if (F16) acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[kk * 2 + i]), __builtin_bit_cast(f16x8, b[kk * 4 + j]), acc[i * 4 + j], 0, 0, 0);
                     else     acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kk * 2 + i]), __builtin_bit_cast(bf16x8, b[kk * 4 + j]), acc[i * 4 + j], 0, 0, 0);
                 }
+        for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(4);     // idle 256 cycles per unit: a convolution's matrix duty instead of 100 %
     }
     float s = 0.f;
 #pragma unroll
@@ -60,30 +92,31 @@ int main(int argc, char** argv) {
     const double secs = argc > 2 ? atof(argv[2]) : 6.0;
     const int wps = argc > 3 ? atoi(argv[3]) : 2;
     const int threads = wps == 1 ? 256 : 512;
+    const int nap = argc > 4 ? atoi(argv[4]) : 0;
     unsigned short* h = (unsigned short*)malloc(65536 * 16);
     srand(1);
     for (int i = 0; i < 65536 * 8; ++i) {     // ~N(0, 1): sum of 4 uniforms
         float v = 0.f; for (int k = 0; k < 4; ++k) v += (float)rand() / RAND_MAX - 0.5f;
-        h[i] = f2h(v * 1.7f, f16);
+        h[i] = f2h(v * 1.7f, f16 == 1);
     }
     uint4* d; float* o;
     hipMalloc(&d, 65536 * 16); hipMalloc(&o, 4096);
     hipMemcpy(d, h, 65536 * 16, hipMemcpyHostToDevice);
-    auto kern = f16 ? soak<1> : soak<0>;
+    auto kern = f16 == 2 ? soak16 : f16 ? soak<1> : soak<0>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16);
     long iters = 20000;
-    hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 8192 * 16, 0, d, o, iters); hipDeviceSynchronize();
+    hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 8192 * 16, 0, d, o, iters, nap); hipDeviceSynchronize();
     double total_flop = 0, total_s = 0;
     auto t0 = std::chrono::steady_clock::now();
     while (true) {
         auto a0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 8192 * 16, 0, d, o, iters); hipDeviceSynchronize();
+        hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 8192 * 16, 0, d, o, iters, nap); hipDeviceSynchronize();
         auto a1 = std::chrono::steady_clock::now();
         const double dt = std::chrono::duration<double>(a1 - a0).count();
-        total_s += dt; total_flop += (double)iters * 16 * 32768.0 * (threads / 64) * 256;
+        total_s += dt; total_flop += (double)iters * (f16 == 2 ? 32 * 16384.0 : 16 * 32768.0) * (threads / 64) * 256;
         if (std::chrono::duration<double>(a1 - t0).count() > secs) break;
         if (dt < 0.5) iters *= 2;
     }
-    printf("%s %d wave(s) per SIMD: %.1f TFLOP/s over %.1f s (%.3f of 2500)\n", f16 ? "f16 " : "bf16", wps, total_flop / total_s / 1e12, total_s, total_flop / total_s / 2.5e15);
+    printf("%s %d wave(s) per SIMD, nap %d: %.1f TFLOP/s over %.1f s (%.3f of 2500)\n", f16 == 2 ? "bf16 16x16x32" : f16 ? "f16 " : "bf16", wps, nap, total_flop / total_s / 1e12, total_s, total_flop / total_s / 2.5e15);
     return 0;
 }

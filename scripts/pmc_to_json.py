@@ -56,8 +56,9 @@ if ttot > 0:
     res["effective_clock_note"] = "GRBM_GUI_ACTIVE / 8 XCDs / kernel-trace duration of the same (counter) pass; dispatches are serialised under --pmc"
 # provenance: bench.py quotes hbm_bytes_per_launch only while the kernel source is the one these counters were collected on
 import hashlib
-_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "universal_speech_enhancement_amd", "csrc", "use_conv_v4.hip")
-res["kernel_source"] = "universal_speech_enhancement_amd/csrc/use_conv_v4.hip"
+_file = "use_conv_v5.hip" if "conv_v5" in filt else "use_conv_v4.hip"          # the kernel's source file, by the kernel-name filter
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "universal_speech_enhancement_amd", "csrc", _file)
+res["kernel_source"] = "universal_speech_enhancement_amd/csrc/" + _file
 res["kernel_source_sha16"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16]
 res["raw_avg_per_dispatch"] = avg
 json.dump(res, open(out, "w"), indent=1)

@@ -952,6 +952,7 @@ int use_set_option(const char* name, long long value) {
     if (!strcmp(name, "stats_part")) { g_stats_part = (int)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "gn_inline")) { g_gn_inline = (long)value; return USE_OK; }                  // takes effect at the next use_plan
     if (!strcmp(name, "conv_v4_min_blocks")) { conv_v4_set_min_blocks((long)value); return USE_OK; }
+    if (!strcmp(name, "conv_v5")) { conv_v5_set((int)value); return USE_OK; }
     if (!strcmp(name, "fir_strip")) { fir_set_strip((int)value); return USE_OK; }
     if (!strcmp(name, "pyr_ws")) { pyr_conv_set_ws((int)value); return USE_OK; }
     if (!strcmp(name, "wgrad_mfma16")) { wgrad_set_mfma16((int)value); return USE_OK; }
@@ -1700,6 +1701,7 @@ int use_conv_bench(const use_conv_case* c, float* out_host, float* stats_host, d
             case 7: if (!conv_sk_eligible(a)) return -1; launch_conv_sk(a, 0); return 0;
             case 2: if (!conv_v2_eligible(a)) return -1; launch_conv_v2(a, 0); return 0;
             case 4: if (!a.wb || (XC && !a.w2b) || a.H % 16 || a.W % 32) return -1; launch_conv_v4(a, 0); return 0;   // (conv_v4 has no partial tiles)
+            case 5: if (!a.wb || (XC && !a.w2b) || a.H % 16 || a.W % 32 || a.in_dtype == DT_F32) return -1; launch_conv_v5(a, 0); return 0;
             default: return -1;
         }
     };

@@ -100,6 +100,10 @@ void pyr_conv_set_ws(int n);                            // wave-specialised form
 bool conv_v4_eligible(const ConvArgs& a);
 void conv_v4_set_min_blocks(long n);                     // smallest grid conv_v4 is used for (default 80 workgroups per image)
 void launch_conv_v4(const ConvArgs& a, hipStream_t s);
+// the same kernel on v_mfma_f32_16x16x32 (use_conv_v5.hip; 16-bit storage): less energy per FLOP than the 32x32x16 shape
+void conv_v5_set(int on);                                // use_set_option("conv_v5", 0 / 1), default 1
+bool conv_v5_enabled(const ConvArgs& a);                 // for a launch conv_v4_eligible() accepted
+void launch_conv_v5(const ConvArgs& a, hipStream_t s);
 // GroupNorm finalisation for the consumers that take a coefficient array (FIR resampling kernels): per-(b, group) mean / rstd
 // from the per-channel totals of up to two concatenated sources, folded with gamma/beta into coef[b][c] = (a, b): y = a*x + b.
 // Source i is given either as totals st_i [B][C_i][2] or (pt_i != null) as nt_i per-workgroup partial totals pt_i [B][nt_i][C_i][2]

@@ -1032,7 +1032,7 @@ void launch_conv(const ConvArgs& a, hipStream_t s) {
     }
 #endif
     if (conv_sk_eligible(a)) { launch_conv_sk(a, s); return; }
-    if (conv_v4_eligible(a)) { launch_conv_v4(a, s); return; }
+    if (conv_v4_eligible(a)) { if (conv_v5_enabled(a)) launch_conv_v5(a, s); else launch_conv_v4(a, s); return; }
     if (conv_v2_eligible(a)) { launch_conv_v2(a, s); return; }
     launch_conv_generic(a, s);
 }
