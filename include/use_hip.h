@@ -65,7 +65,8 @@ typedef struct use_sampler_config {
 /* Process-wide tuning knobs (no reference counterpart).  "subbatch" (default -1 = by batch size: three sub-batches for 6-11 items, else two; round 5: batch 8 as 3 + 3 + 2 is 1.6 % faster than 4 + 4): batches of >= 4 items are evaluated as
  * sub-batches (>= 2 items each) on separate streams, staggered so that the small-map kernels of one run beside the large convolutions of
  * the others; items never interact inside the network, so results are identical to subbatch = 0 (read at use_plan).  "conv_v4_min_blocks": smallest per-image grid (workgroups) the
- * wide-tile convolution kernel is selected for, default 80; results do not depend on it beyond rounding order.  "stats_part" (default 1): on maps
+ * wide-tile convolution kernel is selected for, default 80; results do not depend on it beyond rounding order.  "conv_v5" (default 1): the wide-tile kernel
+ * on v_mfma_f32_16x16x32 in the 16-bit storage modes (conv_v5_kernel; 0: conv_v4_kernel, v_mfma_f32_32x32x16) - bit-identical results, less energy per FLOP.  "stats_part" (default 1): on maps
  * above "gn_inline" pixels (default 128 x 160) the convolutions write per-workgroup GroupNorm partial totals with plain stores and the
  * finalisation sums them, instead of 64-bit atomics on the item's totals - integer sums either way: bit-identical results (read at use_plan).
  * "fir_strip" (default 1): the res-block down-sampler walks 8- or 4-row strips (0: the 2 x 2 block form; 8 / 4: forced) - bit-identical.

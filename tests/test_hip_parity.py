@@ -1006,6 +1006,33 @@ def test_partial_totals_and_atomic_totals_give_the_same_score_bit_for_bit(engine
     assert torch.equal(outs[1], outs[0])
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_conv_v5_and_conv_v4_give_the_same_score_bit_for_bit(engines, prec):
+    """Round 6: the large-map convolution on v_mfma_f32_16x16x32 (conv_v5_kernel: less energy per FLOP, the default for 16-bit storage) against the
+    same pipeline on v_mfma_f32_32x32x16 (conv_v4_kernel, use_set_option("conv_v5", 0)).  Same products, same fp32 accumulation per 32-channel chunk
+    and tap, same epilogue arithmetic: the whole evaluation agrees bit for bit (as the single-convolution harness does on random data, maxdiff 0).
+    T' = 128 at B = 5 (3 + 2 sub-batches): the 512 x 128 and 256 x 64 levels run on the kernel, with residuals, fused shortcuts, concatenated
+    inputs and the Combine epilogue; the wide-tile threshold lowered to also put the smaller maps on it."""
+    from universal_speech_enhancement_amd.hip_engine import set_option
+    eng = engines[prec]
+    B, Tp = 5, 128
+    x = torch.from_numpy(tnoise.complex_normal(23, "vx", (B, 1, 512, Tp))).cuda() * 0.5
+    y = torch.from_numpy(tnoise.complex_normal(23, "vy", (B, 1, 512, Tp))).cuda() * 0.5
+    t = torch.tensor([0.9, 0.5, 0.2, 0.05, 0.7], device="cuda")
+    outs = {}
+    try:
+        for blocks in (80, 1):
+            set_option("conv_v4_min_blocks", blocks)
+            for mode in (1, 0):
+                set_option("conv_v5", mode)
+                outs[blocks, mode] = eng.score(x, y, t).clone()
+    finally:
+        set_option("conv_v5", 1)
+        set_option("conv_v4_min_blocks", 80)
+    assert torch.isfinite(torch.view_as_real(outs[80, 1])).all()
+    assert torch.equal(outs[80, 1], outs[80, 0]) and torch.equal(outs[1, 1], outs[1, 0])
+
+
 def test_plans_and_graphs_of_recent_shapes_are_kept(engines):
     """A predict run over files of a few distinct lengths: 20 batches cycling through 5 padded lengths build 5 plans and capture 5
     graphs, not 20 (the plans of the most recently used shapes are parked with their graphs, use_engine.cpp: plan cache), and a
